@@ -1,0 +1,176 @@
+/*
+ * nbody.h -- C ABI of the MI355X (gfx950) N-body engine.
+ *
+ * One shared library, libnbody_hip.so, exports everything declared here.  The
+ * signatures use plain pointers and sizes only, so any host language can bind
+ * them (ctypes, cgo, JNI, ...).  Every entry point returns 0 on success and a
+ * non-zero nb_status otherwise; nb_last_error() returns the message of the
+ * last failure on the calling thread.
+ *
+ * What each entry point replaces in kr1s0404/N-body-simulation (paths under
+ * the reference checkout):
+ *
+ *   nb_body / nb_vec2      struct Body / struct Vector
+ *                          src/gpu/BH/barnesHutCuda.cuh:20-35,
+ *                          src/gpu/DS/directSum_kernel.cu:33-48,
+ *                          class Body src/cpu/body.h:22-34
+ *   nb_params              the compile-time constants
+ *                          src/gpu/BH/constants.h:23-44, src/cpu/constants.h:23-34,
+ *                          src/cpu/directSum.h:27-28, src/cpu/barnesHut.h:28-30
+ *   nb_init_scenario       BarnesHutCuda::initSpiralBodies / initRandomBodies /
+ *                          initCollideGalaxy / initSolarSystem
+ *                          src/gpu/BH/barnesHutCuda.cu:73-245
+ *   nb_create/nb_destroy   BarnesHutCuda::BarnesHutCuda(int) / ~BarnesHutCuda
+ *                          src/gpu/BH/barnesHutCuda.cu:23-45;
+ *                          NBody::NBody(int,int,int) src/cpu/nBody.cpp:26-51
+ *   nb_setup               BarnesHutCuda::setup(int) src/gpu/BH/barnesHutCuda.cu:258-279
+ *   nb_set_bodies          the cudaMemcpy H2D inside setup(), with caller-made state
+ *   nb_step                BarnesHutCuda::update() src/gpu/BH/barnesHutCuda.cu:280-287,
+ *                          the DirectSumTiledKernel launch
+ *                          src/gpu/DS/directSum_kernel.cu:294-299,
+ *                          Algorithm::update() src/cpu/algorithm.h:31
+ *   nb_read_bodies         readDeviceBodies() + getBodies()
+ *                          src/gpu/BH/barnesHutCuda.cu:247-256
+ *   nb_last_error          CHECK_CUDA_ERROR / CHECK_LAST_CUDA_ERROR
+ *                          src/gpu/BH/err.h:21-46 (there: print + exit; here: status + text)
+ *
+ * The reference has no multi-GPU code; nb_set_partition / nb_exchange_* are
+ * additions that let one process per GPU own a slice of the target bodies and
+ * all-gather positions between steps with whatever collective the host uses.
+ */
+#ifndef NBODY_H
+#define NBODY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nb_vec2 {
+    double x;
+    double y;
+} nb_vec2;
+
+/* Same 72-byte layout as the reference's Body (isDynamic@0, mass@8, radius@16,
+ * position@24, velocity@40, acceleration@56). */
+typedef struct nb_body {
+    uint8_t is_dynamic;
+    uint8_t pad_[7];
+    double mass;
+    double radius;
+    nb_vec2 position;
+    nb_vec2 velocity;
+    nb_vec2 acceleration;
+} nb_body;
+
+enum nb_alg { NB_ALG_DIRECT = 0, NB_ALG_BARNES_HUT = 1 };
+
+/* Scenario numbering of the GPU Barnes-Hut program (src/gpu/BH/barnesHutCuda.cu:258-275),
+ * a superset of the CPU and direct-sum programs' 0/1/2 = spiral/random/solar. */
+enum nb_scenario { NB_SIM_SPIRAL = 0, NB_SIM_RANDOM = 1, NB_SIM_COLLISION = 2, NB_SIM_SOLAR = 3 };
+
+enum nb_status {
+    NB_OK = 0,
+    NB_ERR_ARG = 1,      /* bad argument */
+    NB_ERR_HIP = 2,      /* a HIP runtime call failed */
+    NB_ERR_STATE = 3,    /* call order (e.g. step before bodies were set) */
+    NB_ERR_NOMEM = 4,
+    NB_ERR_OVERFLOW = 5  /* an internal capacity was exceeded; state is unchanged */
+};
+
+typedef struct nb_params {
+    double gravity;       /* GRAVITY      6.67e-11 */
+    double eps;           /* E / epsilon  0.5: r = sqrt(dx^2+dy^2+eps^2), f = G m / (r^3 + eps^2) */
+    double dt;            /* DT           25000 */
+    double theta;         /* THETA        0.5 (Barnes-Hut opening ratio, cell x-width / distance) */
+    double collision_th;  /* COLLISION_TH 1.0e10: pairs closer than r_i + r_j + this are skipped */
+    double bbox_margin;   /* the 1.0e10 pad added round the bounding box (barnesHut.cpp:28-31) */
+} nb_params;
+
+typedef struct nb_sim nb_sim; /* opaque */
+
+/* Fills *p with the reference's constants. */
+void nb_default_params(nb_params *p);
+
+/* Host only, no GPU: writes the initial state of scenario `sim` for n bodies
+ * (NB_SIM_SOLAR always writes 5 and needs n >= 5).  Uses glibc srand(seed)/rand()
+ * in the reference's draw order, so equal seeds give the reference's stream. */
+int nb_init_scenario(int sim, int n, unsigned seed, nb_body *out);
+
+/* Creates a simulation of n bodies on the current HIP device.  params may be
+ * NULL (defaults).  alg is an nb_alg. */
+int nb_create(const nb_params *params, int n, int alg, nb_sim **out);
+int nb_destroy(nb_sim *sim);
+
+/* nb_init_scenario + nb_set_bodies. */
+int nb_setup(nb_sim *sim, int scenario, unsigned seed);
+
+/* Uploads caller-made state (n must equal the n given to nb_create). */
+int nb_set_bodies(nb_sim *sim, const nb_body *bodies, int n);
+
+/* Advances nsteps steps: accelerations from the current positions, then
+ * v += a dt, x += v dt.  Asynchronous on the simulation's stream. */
+int nb_step(nb_sim *sim, int nsteps);
+
+/* Accelerations of the current state without integrating (also stored so that
+ * nb_read_bodies returns them). */
+int nb_compute_accel(nb_sim *sim);
+
+/* Copies the current state (acceleration = the one used by the last step) to
+ * out[0..n), in the order the bodies were given.  Synchronises the stream. */
+int nb_read_bodies(nb_sim *sim, nb_body *out);
+
+/* Blocks until the stream has drained. */
+int nb_sync(nb_sim *sim);
+
+/* Use the caller's hipStream_t (passed as void*) for all work of this handle. */
+int nb_set_stream(nb_sim *sim, void *hip_stream);
+
+/* ---- multi-GPU: one process per GPU, every process holds all n bodies ---- */
+
+/* This process integrates only the bodies whose position in the exchange order
+ * lies in [rank*chunk, min(n,(rank+1)*chunk)), chunk = nb_exchange_chunk().
+ * Must be called after the bodies were set and before the first step. */
+int nb_set_partition(nb_sim *sim, int rank, int world);
+
+/* Device pointer to the exchange buffer: world * chunk records of 2 doubles
+ * (x, y), record k*chunk+i being body i of rank k's slice.  After
+ * nb_step_local() the own slice holds the new positions; the host all-gathers
+ * the buffer in place (every rank contributes chunk records at offset
+ * rank*chunk) and then calls nb_step_finish(). */
+int nb_exchange_buffer(nb_sim *sim, void **device_ptr, size_t *chunk_records, size_t *record_bytes);
+int nb_step_local(nb_sim *sim);
+int nb_step_finish(nb_sim *sim);
+
+/* ---- introspection used by the tests and the benchmark ---- */
+
+enum nb_debug_array {
+    NB_DBG_BBOX = 0,        /* 4 doubles: topLeft.x, topLeft.y, botRight.x, botRight.y */
+    NB_DBG_KEYS = 1,        /* n uint64: Morton key per body, unsorted, exchange order */
+    NB_DBG_SORTED_KEYS = 2, /* n uint64 */
+    NB_DBG_SORTED_IDX = 3,  /* n uint32: exchange-order index of the k-th sorted body */
+    NB_DBG_NODE_RANGE = 4,  /* nnodes x 2 uint32: first sorted body, body count */
+    NB_DBG_NODE_CHILD = 5,  /* nnodes x 2 uint32: first child node, child count */
+    NB_DBG_NODE_COM = 6,    /* nnodes x 4 doubles: com.x, com.y, mass, cell x-width (0 for a leaf) */
+    NB_DBG_LEVEL_START = 7, /* 65 uint32: first node of each tree level, then total */
+    NB_DBG_ORDER = 8,       /* n uint32: caller index of the body at each exchange-order slot */
+    NB_DBG_COUNTERS = 9     /* 8 uint64: [0] body-node evaluations, [1] accepted interactions,
+                               [2] nodes, [3] tree levels, of the last Barnes-Hut step */
+};
+/* Copies the array into out (bytes = capacity of out); *written gets the size. */
+int nb_debug_read(nb_sim *sim, int which, void *out, size_t bytes, size_t *written);
+
+/* Milliseconds spent per stage in the last nb_step(sim, 1) when timing is on:
+ * [0] bbox [1] keys [2] sort [3] build [4] com [5] force+integrate [6] other. */
+int nb_set_stage_timing(nb_sim *sim, int on);
+int nb_stage_ms(nb_sim *sim, float *out, int count);
+
+const char *nb_last_error(void);
+const char *nb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_H */

@@ -1,0 +1,63 @@
+/*
+ * nbody_oracle.h -- TEST INFRASTRUCTURE, not product code.
+ *
+ * A plain-C, double-precision, single-threaded restatement of the reference's
+ * CPU algorithms (kr1s0404/N-body-simulation, src/cpu) and of its scenario
+ * generators.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the HIP library never does.
+ *
+ * Parity pin: every function here is checked by tests/test_oracle_golden.py
+ * against outputs of the reference's own CPU classes compiled unmodified
+ * (oracle/Makefile -> oracle/_ref/libnbody_ref.so) and stored in tests/golden/.
+ */
+#ifndef NBODY_ORACLE_H
+#define NBODY_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Layout of the reference's Body (src/cpu/body.h:22-34 on x86-64). */
+typedef struct orc_body {
+    uint8_t is_dynamic;
+    uint8_t pad_[7];
+    double mass, radius;
+    double px, py, vx, vy, ax, ay;
+} orc_body;
+
+typedef struct orc_params {
+    double gravity, eps, dt, theta, collision_th, bbox_margin;
+} orc_params;
+
+void orc_default_params(orc_params *p);
+
+/* Scenarios 0 spiral, 1 random, 2 collision, 3 solar (GPU-BH numbering). */
+int orc_init_scenario(int sim, int n, unsigned seed, orc_body *out);
+
+/* Direct sum: accelerations of targets [t0,t1) from all n bodies (acc = 2 doubles per target). */
+void orc_direct_accel(const orc_params *p, int n, const orc_body *b, int t0, int t1, double *acc);
+/* Same for an arbitrary list of targets. */
+void orc_direct_accel_list(const orc_params *p, int n, const orc_body *b, int nt, const int *targets, double *acc);
+/* nsteps of DirectSum::update on b in place. */
+void orc_direct_step(const orc_params *p, int n, orc_body *b, int nsteps);
+
+/* Barnes-Hut: bounding box as the reference rounds it (4 doubles tl.x tl.y br.x br.y). */
+void orc_bh_bbox(const orc_params *p, int n, const orc_body *b, double *box);
+/* Accelerations of every body (static bodies keep b[i].ax, b[i].ay); returns 0, or -1 when
+ * two bodies coincide (the reference recurses without end there). stats may be NULL:
+ * [0] node visits, [1] accepted cells + leaf bodies, [2] max depth, [3] tree nodes. */
+int orc_bh_accel(const orc_params *p, int n, const orc_body *b, double *acc, double *stats);
+/* nsteps of BarnesHut::update on b in place; returns 0 or -1 as above. */
+int orc_bh_step(const orc_params *p, int n, orc_body *b, int nsteps);
+
+/* 2x31-bit quadrant path of each body by the reference's midpoint descent from box:
+ * digit at level l (0 = root split) sits in bits [61-2l, 60-2l] and is
+ * 2*(below the y midpoint) + (right of the x midpoint). */
+void orc_morton_keys(int n, const orc_body *b, const double *box, uint64_t *keys);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,157 @@
+"""ctypes access to the CPU checkers under oracle/ (test infrastructure only).
+
+`Oracle` wraps oracle/liboracle.so, the plain-C restatement of the reference's CPU
+algorithms.  `Reference` wraps oracle/_ref/libnbody_ref.so, the reference's own CPU
+classes compiled unmodified (present only where oracle/Makefile could build it, or where
+the prebuilt file travelled with the tree).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# Layout of the reference's Body: isDynamic@0, mass@8, radius@16, position@24,
+# velocity@40, acceleration@56; 72 bytes (src/cpu/body.h:22-34).
+BODY_DTYPE = np.dtype(
+    {
+        "names": ["is_dynamic", "mass", "radius", "pos", "vel", "acc"],
+        "formats": [np.uint8, np.float64, np.float64, (np.float64, 2), (np.float64, 2), (np.float64, 2)],
+        "offsets": [0, 8, 16, 24, 40, 56],
+        "itemsize": 72,
+    }
+)
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("gravity", C.c_double),
+        ("eps", C.c_double),
+        ("dt", C.c_double),
+        ("theta", C.c_double),
+        ("collision_th", C.c_double),
+        ("bbox_margin", C.c_double),
+    ]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_bodies(n):
+    return np.zeros(n, dtype=BODY_DTYPE)
+
+
+class Oracle:
+    def __init__(self, path=None):
+        path = path or os.path.join(ROOT, "oracle", "liboracle.so")
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.orc_default_params.argtypes = [C.POINTER(Params)]
+        L.orc_init_scenario.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_void_p]
+        L.orc_init_scenario.restype = C.c_int
+        L.orc_direct_accel.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_direct_accel_list.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_direct_step.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int]
+        L.orc_bh_bbox.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_bh_accel.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bh_accel.restype = C.c_int
+        L.orc_bh_step.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int]
+        L.orc_bh_step.restype = C.c_int
+        L.orc_morton_keys.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def params(self, **kw):
+        p = Params()
+        self.lib.orc_default_params(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    def scenario(self, sim, n, seed=12345):
+        m = 5 if sim == 3 else n
+        b = make_bodies(m)
+        rc = self.lib.orc_init_scenario(sim, m, seed, _ptr(b))
+        if rc != 0:
+            raise ValueError("orc_init_scenario failed")
+        return b
+
+    def direct_accel(self, b, p=None, t0=0, t1=None):
+        p = p or self.params()
+        n = len(b)
+        t1 = n if t1 is None else t1
+        acc = np.zeros((t1 - t0, 2))
+        self.lib.orc_direct_accel(C.byref(p), n, _ptr(b), t0, t1, _ptr(acc))
+        return acc
+
+    def direct_accel_list(self, b, targets, p=None):
+        p = p or self.params()
+        t = np.ascontiguousarray(targets, dtype=np.int32)
+        acc = np.zeros((len(t), 2))
+        self.lib.orc_direct_accel_list(C.byref(p), len(b), _ptr(b), len(t), _ptr(t), _ptr(acc))
+        return acc
+
+    def direct_step(self, b, nsteps, p=None):
+        p = p or self.params()
+        b = b.copy()
+        self.lib.orc_direct_step(C.byref(p), len(b), _ptr(b), nsteps)
+        return b
+
+    def bh_bbox(self, b, p=None):
+        p = p or self.params()
+        box = np.zeros(4)
+        self.lib.orc_bh_bbox(C.byref(p), len(b), _ptr(b), _ptr(box))
+        return box
+
+    def bh_accel(self, b, p=None, with_stats=False):
+        p = p or self.params()
+        acc = np.zeros((len(b), 2))
+        stats = np.zeros(4)
+        rc = self.lib.orc_bh_accel(C.byref(p), len(b), _ptr(b), _ptr(acc), _ptr(stats))
+        if rc != 0:
+            raise ValueError("coincident bodies")
+        return (acc, stats) if with_stats else acc
+
+    def bh_step(self, b, nsteps, p=None):
+        p = p or self.params()
+        b = b.copy()
+        rc = self.lib.orc_bh_step(C.byref(p), len(b), _ptr(b), nsteps)
+        if rc != 0:
+            raise ValueError("coincident bodies")
+        return b
+
+    def morton_keys(self, b, box):
+        keys = np.zeros(len(b), dtype=np.uint64)
+        box = np.ascontiguousarray(box, dtype=np.float64)
+        self.lib.orc_morton_keys(len(b), _ptr(b), _ptr(box), _ptr(keys))
+        return keys
+
+
+class Reference:
+    """The reference's own CPU classes (src/cpu), compiled unmodified."""
+
+    @staticmethod
+    def path():
+        return os.path.join(ROOT, "oracle", "_ref", "libnbody_ref.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.path())
+
+    def __init__(self):
+        self.lib = C.CDLL(self.path())
+        self.lib.ref_init_scenario.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_void_p]
+        self.lib.ref_init_scenario.restype = C.c_int
+        self.lib.ref_step.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
+        self.lib.ref_step.restype = C.c_int
+
+    def scenario(self, sim_cpu, n, seed=12345):
+        """sim_cpu: 0 spiral, 1 random, 2 solar (the CPU program's numbering)."""
+        b = make_bodies(max(n, 5))
+        m = self.lib.ref_init_scenario(sim_cpu, n, seed, _ptr(b))
+        return b[:m].copy()
+
+    def step(self, alg, b, nsteps):
+        b = b.copy()
+        self.lib.ref_step(alg, len(b), _ptr(b), nsteps)
+        return b
