@@ -1,0 +1,232 @@
+"""Python host side of the MI355X N-body engine: a ctypes binding of the C ABI in
+include/nbody.h (libnbody_hip.so, hand-written HIP for gfx950).
+
+The classes mirror the reference's simulation objects so that tests read like a user of
+the reference would write them:
+
+    reference (src/gpu/BH/barnesHutCuda.cuh:49-80)      here
+    BarnesHutCuda(n)                                    NBodySim(n, alg=BARNES_HUT)
+    setup(sim)                                          .setup(sim, seed)
+    update()                                            .update()
+    readDeviceBodies(); getBodies()                     .read_bodies()
+
+    reference (src/cpu/nBody.h:25-37)                   NBody(n, alg, sim)  (same argument order)
+
+There is no CPU fallback: importing works anywhere, but creating a simulation needs the
+shared library and a HIP device, and raises otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnbody_hip.so")
+
+DIRECT, BARNES_HUT = 0, 1
+SPIRAL, RANDOM, COLLISION, SOLAR = 0, 1, 2, 3
+
+# Same 72-byte layout as the reference's Body.
+BODY_DTYPE = np.dtype(
+    {
+        "names": ["is_dynamic", "mass", "radius", "pos", "vel", "acc"],
+        "formats": [np.uint8, np.float64, np.float64, (np.float64, 2), (np.float64, 2), (np.float64, 2)],
+        "offsets": [0, 8, 16, 24, 40, 56],
+        "itemsize": 72,
+    }
+)
+
+DBG_BBOX, DBG_KEYS, DBG_SORTED_KEYS, DBG_SORTED_IDX = 0, 1, 2, 3
+DBG_NODE_RANGE, DBG_NODE_CHILD, DBG_NODE_COM, DBG_LEVEL_START, DBG_ORDER, DBG_COUNTERS = 4, 5, 6, 7, 8, 9
+
+# Every symbol include/nbody.h declares.
+ABI_SYMBOLS = [
+    "nb_default_params", "nb_init_scenario", "nb_create", "nb_destroy", "nb_setup", "nb_set_bodies",
+    "nb_step", "nb_compute_accel", "nb_read_bodies", "nb_sync", "nb_set_stream", "nb_set_partition",
+    "nb_exchange_buffer", "nb_step_local", "nb_step_finish", "nb_debug_read", "nb_set_stage_timing",
+    "nb_stage_ms", "nb_last_error", "nb_version",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("gravity", C.c_double),
+        ("eps", C.c_double),
+        ("dt", C.c_double),
+        ("theta", C.c_double),
+        ("collision_th", C.c_double),
+        ("bbox_margin", C.c_double),
+    ]
+
+
+class NBodyError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libnbody_hip.so and declares the prototypes; raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise NBodyError(
+            "%s is missing: build it with `make -C n-body-simulation_amd` (hipcc, gfx950); "
+            "there is no CPU fallback" % path
+        )
+    lib = C.CDLL(path)
+    vp, i, u = C.c_void_p, C.c_int, C.c_uint
+    lib.nb_default_params.argtypes = [C.POINTER(Params)]
+    lib.nb_default_params.restype = None
+    lib.nb_init_scenario.argtypes = [i, i, u, vp]
+    lib.nb_create.argtypes = [C.POINTER(Params), i, i, C.POINTER(vp)]
+    lib.nb_destroy.argtypes = [vp]
+    lib.nb_setup.argtypes = [vp, i, u]
+    lib.nb_set_bodies.argtypes = [vp, vp, i]
+    lib.nb_step.argtypes = [vp, i]
+    lib.nb_compute_accel.argtypes = [vp]
+    lib.nb_read_bodies.argtypes = [vp, vp]
+    lib.nb_sync.argtypes = [vp]
+    lib.nb_set_stream.argtypes = [vp, vp]
+    lib.nb_set_partition.argtypes = [vp, i, i]
+    lib.nb_exchange_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.nb_step_local.argtypes = [vp]
+    lib.nb_step_finish.argtypes = [vp]
+    lib.nb_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.nb_set_stage_timing.argtypes = [vp, i]
+    lib.nb_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]
+    lib.nb_last_error.restype = C.c_char_p
+    lib.nb_version.restype = C.c_char_p
+    for name in ABI_SYMBOLS:
+        f = getattr(lib, name)
+        if name not in ("nb_default_params", "nb_last_error", "nb_version"):
+            f.restype = i
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise NBodyError("nbody error %d: %s" % (rc, load_library().nb_last_error().decode()))
+
+
+def default_params(**overrides):
+    p = Params()
+    load_library().nb_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def make_bodies(n):
+    return np.zeros(n, dtype=BODY_DTYPE)
+
+
+def init_scenario(sim, n, seed=12345):
+    """Host-only initial conditions (BarnesHutCuda::init*Bodies); SOLAR always has 5 bodies."""
+    m = 5 if sim == SOLAR else n
+    b = make_bodies(m)
+    _check(load_library().nb_init_scenario(sim, m, seed, b.ctypes.data_as(C.c_void_p)))
+    return b
+
+
+class NBodySim:
+    """One simulation on the current HIP device (the role of the reference's BarnesHutCuda)."""
+
+    def __init__(self, n, alg=BARNES_HUT, params=None, stream=None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.n = int(n)
+        self.alg = alg
+        self.params = params or default_params()
+        _check(self._lib.nb_create(C.byref(self.params), self.n, alg, C.byref(self._h)))
+        if stream is not None:
+            _check(self._lib.nb_set_stream(self._h, C.c_void_p(stream)))
+
+    # -- reference surface --
+    def setup(self, sim, seed=12345):
+        _check(self._lib.nb_setup(self._h, sim, seed))
+
+    def update(self, nsteps=1):
+        _check(self._lib.nb_step(self._h, nsteps))
+
+    def read_bodies(self):
+        out = make_bodies(self.n)
+        _check(self._lib.nb_read_bodies(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # -- additions --
+    def set_bodies(self, bodies):
+        b = np.ascontiguousarray(bodies, dtype=BODY_DTYPE)
+        _check(self._lib.nb_set_bodies(self._h, b.ctypes.data_as(C.c_void_p), len(b)))
+
+    def compute_accel(self):
+        _check(self._lib.nb_compute_accel(self._h))
+        return self.read_bodies()["acc"]
+
+    def sync(self):
+        _check(self._lib.nb_sync(self._h))
+
+    def set_partition(self, rank, world):
+        _check(self._lib.nb_set_partition(self._h, rank, world))
+
+    def exchange_buffer(self):
+        """(device pointer, records per rank, bytes per record) of the position exchange buffer."""
+        p, c, r = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _check(self._lib.nb_exchange_buffer(self._h, C.byref(p), C.byref(c), C.byref(r)))
+        return p.value, c.value, r.value
+
+    def step_local(self):
+        _check(self._lib.nb_step_local(self._h))
+
+    def step_finish(self):
+        _check(self._lib.nb_step_finish(self._h))
+
+    def set_stage_timing(self, on=True):
+        _check(self._lib.nb_set_stage_timing(self._h, 1 if on else 0))
+
+    def stage_ms(self):
+        out = (C.c_float * 8)()
+        _check(self._lib.nb_stage_ms(self._h, out, 8))
+        names = ["bbox", "keys", "sort", "build", "com", "force", "other"]
+        return {k: out[i] for i, k in enumerate(names)}
+
+    def debug(self, which, dtype, count):
+        out = np.zeros(count, dtype=dtype)
+        w = C.c_size_t()
+        _check(self._lib.nb_debug_read(self._h, which, out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(w)))
+        return out[: w.value // out.itemsize]
+
+    def close(self):
+        if self._h:
+            self._lib.nb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class NBody(NBodySim):
+    """The CPU program's object, same argument order: NBody(n, alg, sim) (src/cpu/nBody.cpp:26-51);
+    sim uses the CPU numbering 0 spiral, 1 random, anything else solar (n forced to 5)."""
+
+    def __init__(self, n, alg, sim, seed=12345, params=None):
+        scenario = {0: SPIRAL, 1: RANDOM}.get(sim, SOLAR)
+        if scenario == SOLAR:
+            n = 5
+        super().__init__(n, alg, params)
+        self.setup(scenario, seed)

@@ -1,0 +1,172 @@
+// microbench.hip -- measures the FP32 vector-ALU rates the direct-sum kernel is priced
+// against on gfx950: v_fma_f32, v_pk_fma_f32, v_rsq_f32 and a mix shaped like one pair
+// interaction, at 1/2/4/8 waves per SIMD.  Stand-alone diagnostic (not part of the library):
+//   hipcc -O3 --offload-arch=gfx950 microbench.hip -o microbench && ./microbench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+#define CHECK(x)                                                                           \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));      \
+            exit(1);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+constexpr int ITERS = 4096;
+
+// 8 independent v_fma_f32 per iteration
+__global__ void k_fma(float *out, float b, float c)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_fma_f32 %0, %0, %8, %9\n\t"
+                     "v_fma_f32 %1, %1, %8, %9\n\t"
+                     "v_fma_f32 %2, %2, %8, %9\n\t"
+                     "v_fma_f32 %3, %3, %8, %9\n\t"
+                     "v_fma_f32 %4, %4, %8, %9\n\t"
+                     "v_fma_f32 %5, %5, %8, %9\n\t"
+                     "v_fma_f32 %6, %6, %8, %9\n\t"
+                     "v_fma_f32 %7, %7, %8, %9"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(b), "v"(c));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+// 8 independent v_pk_fma_f32 per iteration (two FMAs each)
+__global__ void k_pkfma(float *out, float b, float c)
+{
+    float2v bb = {b, b}, cc = {c, c};
+    float t = threadIdx.x;
+    float2v a0 = {t, t + 1}, a1 = {t + 2, t + 3}, a2 = {t + 4, t + 5}, a3 = {t + 6, t + 7};
+    float2v a4 = {t + 8, t + 9}, a5 = {t + 10, t + 11}, a6 = {t + 12, t + 13}, a7 = {t + 14, t + 15};
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n\t"
+                     "v_pk_fma_f32 %1, %1, %8, %9\n\t"
+                     "v_pk_fma_f32 %2, %2, %8, %9\n\t"
+                     "v_pk_fma_f32 %3, %3, %8, %9\n\t"
+                     "v_pk_fma_f32 %4, %4, %8, %9\n\t"
+                     "v_pk_fma_f32 %5, %5, %8, %9\n\t"
+                     "v_pk_fma_f32 %6, %6, %8, %9\n\t"
+                     "v_pk_fma_f32 %7, %7, %8, %9"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(bb), "v"(cc));
+    }
+    float2v s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
+}
+
+// 8 independent v_rsq_f32 per iteration
+__global__ void k_rsq(float *out, float b, float c)
+{
+    float a0 = threadIdx.x + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_rsq_f32 %0, %0\n\t"
+                     "v_rsq_f32 %1, %1\n\t"
+                     "v_rsq_f32 %2, %2\n\t"
+                     "v_rsq_f32 %3, %3\n\t"
+                     "v_rsq_f32 %4, %4\n\t"
+                     "v_rsq_f32 %5, %5\n\t"
+                     "v_rsq_f32 %6, %6\n\t"
+                     "v_rsq_f32 %7, %7"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b + c;
+}
+
+// 1 v_rsq_f32 + 6 v_fma_f32 interleaved, 2 chains (does the transcendental overlap the FMAs?)
+__global__ void k_mix(float *out, float b, float c)
+{
+    float a0 = threadIdx.x + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_rsq_f32 %0, %0\n\t"
+                     "v_fma_f32 %1, %1, %8, %9\n\t"
+                     "v_fma_f32 %2, %2, %8, %9\n\t"
+                     "v_fma_f32 %3, %3, %8, %9\n\t"
+                     "v_rsq_f32 %4, %4\n\t"
+                     "v_fma_f32 %5, %5, %8, %9\n\t"
+                     "v_fma_f32 %6, %6, %8, %9\n\t"
+                     "v_fma_f32 %7, %7, %8, %9"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(b), "v"(c));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+// v_cmp + v_cndmask pairs (cost of the cutoff select), 4 pairs per iteration
+__global__ void k_cmpsel(float *out, float b, float c)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_cmp_gt_f32 vcc, %0, %4\n\t"
+                     "v_cndmask_b32 %0, %5, %0, vcc\n\t"
+                     "v_cmp_gt_f32 vcc, %1, %4\n\t"
+                     "v_cndmask_b32 %1, %5, %1, vcc\n\t"
+                     "v_cmp_gt_f32 vcc, %2, %4\n\t"
+                     "v_cndmask_b32 %2, %5, %2, vcc\n\t"
+                     "v_cmp_gt_f32 vcc, %3, %4\n\t"
+                     "v_cndmask_b32 %3, %5, %3, vcc"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                     : "v"(b), "v"(c)
+                     : "vcc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+
+template <typename K>
+static double run(K kernel, int blocks, float *out, int reps)
+{
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e-3 / reps;
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    int cus = prop.multiProcessorCount;
+    double clk = prop.clockRate * 1e3;
+    printf("device %s CUs %d clock %.0f MHz\n", prop.name, cus, clk / 1e6);
+    float *out;
+    CHECK(hipMalloc(&out, sizeof(float) * 256 * cus * 16));
+    const int reps = 20;
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        int blocks = cus * wps;  // 256-thread blocks: one wave per SIMD each
+        double lanes = (double)blocks * 256;
+        double t;
+        t = run(k_fma, blocks, out, reps);
+        double fma_rate = lanes * ITERS * 8 / t;
+        t = run(k_pkfma, blocks, out, reps);
+        double pk_rate = lanes * ITERS * 8 * 2 / t;
+        t = run(k_rsq, blocks, out, reps);
+        double rsq_rate = lanes * ITERS * 8 / t;
+        t = run(k_mix, blocks, out, reps);
+        double mix_rate = lanes * ITERS * 8 / t;
+        t = run(k_cmpsel, blocks, out, reps);
+        double sel_rate = lanes * ITERS * 8 / t;
+        printf("waves/SIMD %d: fma %.2f Tlane-op/s (%.1f TFLOP/s, %.1f lane-op/clk/CU) | pk_fma %.2f Tfma/s (%.1f TFLOP/s) | "
+               "rsq %.2f T/s | mix(2rsq+6fma) %.2f Tinst/s | cmp+cndmask %.2f Tinst/s\n",
+               wps, fma_rate / 1e12, 2 * fma_rate / 1e12, fma_rate / clk / cus, pk_rate / 1e12, 2 * pk_rate / 1e12,
+               rsq_rate / 1e12, mix_rate / 1e12, sel_rate / 1e12);
+    }
+    CHECK(hipFree(out));
+    return 0;
+}

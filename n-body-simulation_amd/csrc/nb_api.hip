@@ -1,0 +1,630 @@
+// nb_api.hip -- the C ABI of libnbody_hip.so (declared in include/nbody.h).
+//
+// nb_sim plays the role of the reference's BarnesHutCuda object
+// (src/gpu/BH/barnesHutCuda.cuh:49-80): it owns the device arrays, takes the initial
+// state once (setup) and advances it with update()-like steps, copying bodies back only
+// when asked.  State on the device is SoA: positions and velocities in FP64 (the
+// reference's precision, so integration adds no rounding of its own), and per step a
+// float4 record per body for the FP32 force kernels.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "nb_bh.h"
+#include "nb_common.h"
+
+namespace nb {
+
+static thread_local std::string g_error;
+
+void set_error(const std::string &msg) { g_error = msg; }
+
+int fail(int status, const std::string &msg)
+{
+    g_error = msg;
+    return status;
+}
+
+}  // namespace nb
+
+using namespace nb;
+
+struct nb_sim {
+    nb_params p;
+    int n = 0;
+    int alg = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool have_bodies = false;
+
+    Units units{};
+    ForceConsts fc{};
+
+    // state in exchange order; pos has room for world*chunk records
+    size_t cap = 0;
+    double2 *pos = nullptr, *vel = nullptr, *acc = nullptr;
+    double *mass = nullptr, *radius = nullptr;
+    uint8_t *dyn = nullptr;
+    float4 *posm[2] = {nullptr, nullptr};
+    float *rad_s = nullptr;
+    int cur = 0;
+    std::vector<uint32_t> order;  // caller index of the body in each exchange-order slot
+
+    // partition
+    int rank = 0, world = 1;
+    size_t chunk = 0;
+    int t0 = 0, t1 = 0;
+    bool mid_step = false;
+
+    // direct sum
+    double2 *part = nullptr;
+    int jsplit = 1;
+
+    // Barnes-Hut
+    BhBuffers bh;
+    int collect_stats = 0;
+
+    // stage timing
+    int timing = 0;
+    hipEvent_t ev[8] = {};
+    float stage_ms[8] = {};
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T *&p, size_t count)
+{
+    void *v = nullptr;
+    hipError_t e = hipMalloc(&v, count * sizeof(T) + 256);
+    if (e != hipSuccess)
+        return fail(NB_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    p = (T *)v;
+    return NB_OK;
+}
+
+double pow2_floor_exp(double v) { return v > 0 ? std::floor(std::log2(v)) : 0.0; }
+
+// Powers of two that bring the largest coordinate to [4, 8) and the largest mass to about 2^20.
+void choose_units(nb_sim *s, const nb_body *b, int n)
+{
+    double maxc = 1.0, maxm = 1.0;
+    for (int i = 0; i < n; ++i) {
+        maxc = std::max(maxc, std::max(std::fabs(b[i].position.x), std::fabs(b[i].position.y)));
+        maxm = std::max(maxm, std::fabs(b[i].mass));
+    }
+    s->units.len_unit = std::ldexp(1.0, (int)pow2_floor_exp(maxc) - 2);
+    s->units.mass_unit = std::ldexp(1.0, (int)pow2_floor_exp(maxm) - 20);
+    s->units.acc_factor = s->p.gravity * s->units.mass_unit / (s->units.len_unit * s->units.len_unit);
+    const double lu = s->units.len_unit;
+    s->fc.eps2 = (float)(s->p.eps * s->p.eps / (lu * lu));
+    s->fc.eps3 = (float)(s->p.eps * s->p.eps / (lu * lu * lu));
+    s->fc.cth = (float)(s->p.collision_th / lu);
+    // Every evaluated pair is farther apart than collision_th, so r^3 >= cth^3: eps3 below
+    // 2^-26 of that cannot change a float sum r^3 + eps3.
+    const double c3 = (double)s->fc.cth * s->fc.cth * s->fc.cth;
+    s->fc.exact_denom = !((double)s->fc.eps3 <= std::ldexp(c3, -26));
+}
+
+IntegrateArgs integrate_args(const nb_sim *s, int do_integrate)
+{
+    IntegrateArgs ia;
+    ia.acc_factor = s->units.acc_factor;
+    ia.dt = s->p.dt;
+    ia.inv_len_unit = 1.0 / s->units.len_unit;
+    ia.do_integrate = do_integrate;
+    return ia;
+}
+
+BhStepArgs bh_args(nb_sim *s, int do_integrate)
+{
+    BhStepArgs a;
+    a.pos = s->pos;
+    a.mass = s->mass;
+    a.radius = s->radius;
+    a.dyn = s->dyn;
+    a.vel = s->vel;
+    a.acc = s->acc;
+    a.pos_out = s->pos;
+    a.n = s->n;
+    a.t0 = s->t0;
+    a.t1 = s->t1;
+    a.units = s->units;
+    a.fc = s->fc;
+    a.ia = integrate_args(s, do_integrate);
+    a.theta = s->p.theta;
+    a.bbox_margin = s->p.bbox_margin;
+    a.collision_th = s->p.collision_th;
+    a.collect_stats = s->collect_stats;
+    return a;
+}
+
+void mark(nb_sim *s, int k)
+{
+    if (s->timing)
+        (void)hipEventRecord(s->ev[k], s->stream);
+}
+
+int step_local(nb_sim *s, int do_integrate)
+{
+    if (s->alg == NB_ALG_DIRECT) {
+        mark(s, 0);
+        NB_TRY(direct_step(s->stream, s->posm[s->cur], s->posm[s->cur ^ 1], s->rad_s, s->n, s->t0, s->t1 - s->t0, s->fc,
+                           integrate_args(s, do_integrate), s->dyn, s->pos, s->vel, s->acc, s->part, s->jsplit));
+        mark(s, 1);
+        return NB_OK;
+    }
+    BhStepArgs a = bh_args(s, do_integrate);
+    mark(s, 0);
+    NB_TRY(bh_bbox(s->stream, s->bh, a));
+    mark(s, 1);
+    NB_TRY(bh_keys(s->stream, s->bh, a));
+    mark(s, 2);
+    NB_TRY(bh_sort(s->stream, s->bh, a));
+    mark(s, 3);
+    NB_TRY(bh_build(s->stream, s->bh, a));
+    mark(s, 4);
+    NB_TRY(bh_com(s->stream, s->bh, a));
+    mark(s, 5);
+    NB_TRY(bh_force(s->stream, s->bh, a));
+    mark(s, 6);
+    return NB_OK;
+}
+
+int step_finish(nb_sim *s)
+{
+    if (s->alg == NB_ALG_DIRECT) {
+        // records of the bodies other ranks advanced come from the gathered positions
+        if (s->world > 1) {
+            const double il = 1.0 / s->units.len_unit, im = 1.0 / s->units.mass_unit;
+            NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, 0, s->t0, il, im, s->p.collision_th,
+                             s->posm[s->cur ^ 1], s->rad_s));
+            NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, s->t1, s->n, il, im, s->p.collision_th,
+                             s->posm[s->cur ^ 1], s->rad_s));
+        }
+        s->cur ^= 1;
+    }
+    return NB_OK;
+}
+
+int collect_timing(nb_sim *s)
+{
+    if (!s->timing)
+        return NB_OK;
+    NB_HIP(hipStreamSynchronize(s->stream));
+    for (int k = 0; k < 8; ++k)
+        s->stage_ms[k] = 0.f;
+    const int last = s->alg == NB_ALG_DIRECT ? 1 : 6;
+    for (int k = 0; k < last; ++k) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->ev[k], s->ev[k + 1]) == hipSuccess)
+            s->stage_ms[s->alg == NB_ALG_DIRECT ? 5 : k] = ms;
+    }
+    return NB_OK;
+}
+
+void release(nb_sim *s)
+{
+    (void)hipFree(s->pos);
+    (void)hipFree(s->vel);
+    (void)hipFree(s->acc);
+    (void)hipFree(s->mass);
+    (void)hipFree(s->radius);
+    (void)hipFree(s->dyn);
+    (void)hipFree(s->posm[0]);
+    (void)hipFree(s->posm[1]);
+    (void)hipFree(s->rad_s);
+    (void)hipFree(s->part);
+    bh_free(s->bh);
+    for (auto &e : s->ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (s->own_stream && s->stream)
+        (void)hipStreamDestroy(s->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *nb_last_error(void) { return g_error.c_str(); }
+
+const char *nb_version(void) { return "nbody_hip 0.1 (gfx950)"; }
+
+int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
+{
+    if (!out)
+        return fail(NB_ERR_ARG, "nb_create: out is NULL");
+    *out = nullptr;
+    if (n < 1)
+        return fail(NB_ERR_ARG, "ERROR: need to have at least 1 body");
+    if (alg != NB_ALG_DIRECT && alg != NB_ALG_BARNES_HUT)
+        return fail(NB_ERR_ARG, "nb_create: alg must be 0 (direct sum) or 1 (Barnes-Hut)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(NB_ERR_HIP, "nb_create: no HIP device is visible; this library has no CPU path");
+    nb_sim *s = new nb_sim();
+    if (params)
+        s->p = *params;
+    else
+        nb_default_params(&s->p);
+    if (!(s->p.theta >= 0) || !(s->p.collision_th >= 0) || !(s->p.eps >= 0)) {
+        delete s;
+        return fail(NB_ERR_ARG, "nb_create: theta, collision_th and eps must be >= 0");
+    }
+    s->n = n;
+    s->alg = alg;
+    s->t0 = 0;
+    s->t1 = n;
+    s->chunk = (size_t)n;
+    s->cap = (size_t)n + 64;
+    int rc = NB_OK;
+    auto chk = [&](int r) {
+        if (rc == NB_OK)
+            rc = r;
+    };
+    if (hipGetDevice(&s->device) != hipSuccess)
+        chk(fail(NB_ERR_HIP, "hipGetDevice failed"));
+    if (rc == NB_OK && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
+        chk(fail(NB_ERR_HIP, "hipStreamCreate failed"));
+    s->own_stream = rc == NB_OK;
+    chk(dev_alloc(s->pos, s->cap));
+    chk(dev_alloc(s->vel, s->cap));
+    chk(dev_alloc(s->acc, s->cap));
+    chk(dev_alloc(s->mass, s->cap));
+    chk(dev_alloc(s->radius, s->cap));
+    chk(dev_alloc(s->dyn, s->cap));
+    if (alg == NB_ALG_DIRECT) {
+        chk(dev_alloc(s->posm[0], s->cap));
+        chk(dev_alloc(s->posm[1], s->cap));
+        chk(dev_alloc(s->rad_s, s->cap));
+        s->jsplit = direct_choose_jsplit(n, n);
+        chk(dev_alloc(s->part, (size_t)s->jsplit * n));
+    } else {
+        chk(bh_alloc(s->bh, n));
+    }
+    for (auto &e : s->ev)
+        if (rc == NB_OK && hipEventCreate(&e) != hipSuccess)
+            chk(fail(NB_ERR_HIP, "hipEventCreate failed"));
+    if (rc != NB_OK) {
+        release(s);
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return NB_OK;
+}
+
+int nb_destroy(nb_sim *s)
+{
+    if (!s)
+        return NB_OK;
+    (void)hipStreamSynchronize(s->stream);
+    release(s);
+    delete s;
+    return NB_OK;
+}
+
+int nb_set_stream(nb_sim *s, void *hip_stream)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_set_stream: sim is NULL");
+    NB_HIP(hipStreamSynchronize(s->stream));
+    if (s->own_stream && s->stream)
+        (void)hipStreamDestroy(s->stream);
+    s->stream = (hipStream_t)hip_stream;
+    s->own_stream = false;
+    return NB_OK;
+}
+
+int nb_set_bodies(nb_sim *s, const nb_body *b, int n)
+{
+    if (!s || !b)
+        return fail(NB_ERR_ARG, "nb_set_bodies: NULL argument");
+    if (n != s->n)
+        return fail(NB_ERR_ARG, "nb_set_bodies: n differs from the n given to nb_create");
+    for (int i = 0; i < n; ++i)
+        if (!std::isfinite(b[i].position.x) || !std::isfinite(b[i].position.y) || !std::isfinite(b[i].mass))
+            return fail(NB_ERR_ARG, "nb_set_bodies: body " + std::to_string(i) + " is not finite");
+    choose_units(s, b, n);
+    s->order.resize(n);
+    std::iota(s->order.begin(), s->order.end(), 0u);
+    std::vector<double2> pos(n), vel(n), acc(n);
+    std::vector<double> mass(n), radius(n);
+    std::vector<uint8_t> dyn(n);
+    for (int k = 0; k < n; ++k) {
+        const nb_body &x = b[s->order[k]];
+        pos[k] = make_double2(x.position.x, x.position.y);
+        vel[k] = make_double2(x.velocity.x, x.velocity.y);
+        acc[k] = make_double2(x.acceleration.x, x.acceleration.y);
+        mass[k] = x.mass;
+        radius[k] = x.radius;
+        dyn[k] = x.is_dynamic ? 1 : 0;
+    }
+    NB_HIP(hipStreamSynchronize(s->stream));
+    NB_HIP(hipMemcpy(s->pos, pos.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+    NB_HIP(hipMemcpy(s->vel, vel.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+    NB_HIP(hipMemcpy(s->acc, acc.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+    NB_HIP(hipMemcpy(s->mass, mass.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    NB_HIP(hipMemcpy(s->radius, radius.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    NB_HIP(hipMemcpy(s->dyn, dyn.data(), n, hipMemcpyHostToDevice));
+    if (s->alg == NB_ALG_DIRECT) {
+        s->cur = 0;
+        NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, 0, n, 1.0 / s->units.len_unit, 1.0 / s->units.mass_unit,
+                         s->p.collision_th, s->posm[0], s->rad_s));
+        // mass and cutoff radius never change: give the second buffer the same records
+        NB_HIP(hipMemcpyAsync(s->posm[1], s->posm[0], sizeof(float4) * n, hipMemcpyDeviceToDevice, s->stream));
+    }
+    NB_HIP(hipStreamSynchronize(s->stream));
+    s->have_bodies = true;
+    s->mid_step = false;
+    return NB_OK;
+}
+
+int nb_setup(nb_sim *s, int scenario, unsigned seed)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_setup: sim is NULL");
+    if (scenario == NB_SIM_SOLAR && s->n != 5)
+        return fail(NB_ERR_ARG, "nb_setup: the solar system has 5 bodies (create the simulation with n = 5)");
+    std::vector<nb_body> b(s->n);
+    NB_TRY(nb_init_scenario(scenario, s->n, seed, b.data()));
+    return nb_set_bodies(s, b.data(), s->n);
+}
+
+int nb_step_local(nb_sim *s)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_step_local: sim is NULL");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb_step_local: no bodies were set");
+    if (s->mid_step)
+        return fail(NB_ERR_STATE, "nb_step_local: the previous step was not finished");
+    NB_TRY(step_local(s, 1));
+    s->mid_step = true;
+    return NB_OK;
+}
+
+int nb_step_finish(nb_sim *s)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_step_finish: sim is NULL");
+    if (!s->mid_step)
+        return fail(NB_ERR_STATE, "nb_step_finish: nb_step_local was not called");
+    NB_TRY(step_finish(s));
+    s->mid_step = false;
+    return NB_OK;
+}
+
+int nb_step(nb_sim *s, int nsteps)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_step: sim is NULL");
+    if (nsteps < 0)
+        return fail(NB_ERR_ARG, "nb_step: nsteps < 0");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb_step: no bodies were set");
+    if (s->world != 1)
+        return fail(NB_ERR_STATE, "nb_step: a partitioned simulation steps with nb_step_local / nb_step_finish");
+    if (s->mid_step)
+        return fail(NB_ERR_STATE, "nb_step: a split step is in flight");
+    for (int k = 0; k < nsteps; ++k) {
+        NB_TRY(step_local(s, 1));
+        NB_TRY(step_finish(s));
+    }
+    if (nsteps > 0)
+        NB_TRY(collect_timing(s));
+    return NB_OK;
+}
+
+int nb_compute_accel(nb_sim *s)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_compute_accel: sim is NULL");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb_compute_accel: no bodies were set");
+    if (s->mid_step)
+        return fail(NB_ERR_STATE, "nb_compute_accel: a split step is in flight");
+    NB_TRY(step_local(s, 0));
+    return collect_timing(s);
+}
+
+int nb_sync(nb_sim *s)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_sync: sim is NULL");
+    NB_HIP(hipStreamSynchronize(s->stream));
+    return NB_OK;
+}
+
+int nb_read_bodies(nb_sim *s, nb_body *out)
+{
+    if (!s || !out)
+        return fail(NB_ERR_ARG, "nb_read_bodies: NULL argument");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb_read_bodies: no bodies were set");
+    const int n = s->n;
+    std::vector<double2> pos(n), vel(n), acc(n);
+    std::vector<double> mass(n), radius(n);
+    std::vector<uint8_t> dyn(n);
+    NB_HIP(hipStreamSynchronize(s->stream));
+    NB_HIP(hipMemcpy(pos.data(), s->pos, sizeof(double2) * n, hipMemcpyDeviceToHost));
+    NB_HIP(hipMemcpy(vel.data(), s->vel, sizeof(double2) * n, hipMemcpyDeviceToHost));
+    NB_HIP(hipMemcpy(acc.data(), s->acc, sizeof(double2) * n, hipMemcpyDeviceToHost));
+    NB_HIP(hipMemcpy(mass.data(), s->mass, sizeof(double) * n, hipMemcpyDeviceToHost));
+    NB_HIP(hipMemcpy(radius.data(), s->radius, sizeof(double) * n, hipMemcpyDeviceToHost));
+    NB_HIP(hipMemcpy(dyn.data(), s->dyn, n, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; ++k) {
+        nb_body &x = out[s->order[k]];
+        std::memset(&x, 0, sizeof(x));
+        x.is_dynamic = dyn[k];
+        x.mass = mass[k];
+        x.radius = radius[k];
+        x.position = {pos[k].x, pos[k].y};
+        x.velocity = {vel[k].x, vel[k].y};
+        x.acceleration = {acc[k].x, acc[k].y};
+    }
+    return NB_OK;
+}
+
+int nb_set_partition(nb_sim *s, int rank, int world)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_set_partition: sim is NULL");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world)
+        return fail(NB_ERR_ARG, "nb_set_partition: need 0 <= rank < world <= 64");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb_set_partition: set the bodies first");
+    if (s->alg == NB_ALG_BARNES_HUT && world > 1)
+        return fail(NB_ERR_STATE, "nb_set_partition: Barnes-Hut runs on one GPU in this version");
+    s->rank = rank;
+    s->world = world;
+    s->chunk = ((size_t)s->n + world - 1) / world;
+    s->t0 = (int)std::min((size_t)s->n, rank * s->chunk);
+    s->t1 = (int)std::min((size_t)s->n, (rank + 1) * s->chunk);
+    return NB_OK;
+}
+
+int nb_exchange_buffer(nb_sim *s, void **device_ptr, size_t *chunk_records, size_t *record_bytes)
+{
+    if (!s || !device_ptr || !chunk_records || !record_bytes)
+        return fail(NB_ERR_ARG, "nb_exchange_buffer: NULL argument");
+    *device_ptr = s->pos;
+    *chunk_records = s->chunk;
+    *record_bytes = sizeof(double2);
+    return NB_OK;
+}
+
+int nb_set_stage_timing(nb_sim *s, int on)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_set_stage_timing: sim is NULL");
+    s->timing = on ? 1 : 0;
+    s->collect_stats = on ? 1 : 0;
+    return NB_OK;
+}
+
+int nb_stage_ms(nb_sim *s, float *out, int count)
+{
+    if (!s || !out)
+        return fail(NB_ERR_ARG, "nb_stage_ms: NULL argument");
+    for (int k = 0; k < count; ++k)
+        out[k] = k < 8 ? s->stage_ms[k] : 0.f;
+    return NB_OK;
+}
+
+int nb_debug_read(nb_sim *s, int which, void *out, size_t bytes, size_t *written)
+{
+    if (!s || !out)
+        return fail(NB_ERR_ARG, "nb_debug_read: NULL argument");
+    NB_HIP(hipStreamSynchronize(s->stream));
+    const void *src = nullptr;
+    size_t need = 0;
+    std::vector<uint32_t> tmp;
+    const bool is_bh = s->alg == NB_ALG_BARNES_HUT;
+    uint32_t ls[BH_MAX_DEPTH + 2] = {};
+    size_t nnodes = 0;
+    if (is_bh) {
+        NB_HIP(hipMemcpy(ls, s->bh.level_start, sizeof(ls), hipMemcpyDeviceToHost));
+        for (int d = 0; d < BH_MAX_DEPTH + 1; ++d)
+            nnodes = std::max(nnodes, (size_t)ls[d + 1]);
+        if (nnodes > s->bh.node_cap)
+            nnodes = 0;  // no tree was built yet
+    }
+    switch (which) {
+    case NB_DBG_ORDER:
+        src = nullptr;
+        need = sizeof(uint32_t) * s->n;
+        if (bytes < need)
+            return fail(NB_ERR_ARG, "nb_debug_read: buffer too small");
+        std::memcpy(out, s->order.data(), need);
+        if (written)
+            *written = need;
+        return NB_OK;
+    case NB_DBG_BBOX:
+        src = s->bh.box;
+        need = 4 * sizeof(double);
+        break;
+    case NB_DBG_KEYS: {
+        // the sort ping-pongs over the unsorted keys; rebuild them from the sorted pairs
+        if (!is_bh)
+            return fail(NB_ERR_STATE, "nb_debug_read: not a Barnes-Hut simulation");
+        need = sizeof(uint64_t) * s->n;
+        if (bytes < need)
+            return fail(NB_ERR_ARG, "nb_debug_read: buffer too small");
+        std::vector<uint64_t> sk(s->n);
+        std::vector<uint32_t> si(s->n);
+        NB_HIP(hipMemcpy(sk.data(), s->bh.keys[s->bh.sorted], need, hipMemcpyDeviceToHost));
+        NB_HIP(hipMemcpy(si.data(), s->bh.idx[s->bh.sorted], sizeof(uint32_t) * s->n, hipMemcpyDeviceToHost));
+        uint64_t *o = (uint64_t *)out;
+        for (int k = 0; k < s->n; ++k)
+            o[si[k]] = sk[k];
+        if (written)
+            *written = need;
+        return NB_OK;
+    }
+    case NB_DBG_SORTED_KEYS:
+        src = s->bh.keys[s->bh.sorted];
+        need = sizeof(uint64_t) * s->n;
+        break;
+    case NB_DBG_SORTED_IDX:
+        src = s->bh.idx[s->bh.sorted];
+        need = sizeof(uint32_t) * s->n;
+        break;
+    case NB_DBG_NODE_RANGE:
+    case NB_DBG_NODE_CHILD: {
+        if (!is_bh)
+            return fail(NB_ERR_STATE, "nb_debug_read: not a Barnes-Hut simulation");
+        need = sizeof(uint32_t) * 2 * nnodes;
+        if (bytes < need)
+            return fail(NB_ERR_ARG, "nb_debug_read: buffer too small");
+        std::vector<uint4> meta(nnodes);
+        NB_HIP(hipMemcpy(meta.data(), s->bh.node_meta, sizeof(uint4) * nnodes, hipMemcpyDeviceToHost));
+        uint32_t *o = (uint32_t *)out;
+        for (size_t u = 0; u < nnodes; ++u) {
+            if (which == NB_DBG_NODE_RANGE) {
+                o[2 * u] = meta[u].x;
+                o[2 * u + 1] = meta[u].y;
+            } else {
+                o[2 * u] = meta[u].z;
+                o[2 * u + 1] = meta[u].w & 0xffu;
+            }
+        }
+        if (written)
+            *written = need;
+        return NB_OK;
+    }
+    case NB_DBG_NODE_COM:
+        src = s->bh.node_com;
+        need = sizeof(double) * 4 * nnodes;
+        break;
+    case NB_DBG_LEVEL_START:
+        need = sizeof(uint32_t) * (BH_MAX_DEPTH + 2);
+        if (bytes < need)
+            return fail(NB_ERR_ARG, "nb_debug_read: buffer too small");
+        std::memcpy(out, ls, need);
+        if (written)
+            *written = need;
+        return NB_OK;
+    case NB_DBG_COUNTERS:
+        src = s->bh.counters;
+        need = sizeof(unsigned long long) * 8;
+        break;
+    default:
+        return fail(NB_ERR_ARG, "nb_debug_read: unknown array");
+    }
+    if (!is_bh)
+        return fail(NB_ERR_STATE, "nb_debug_read: not a Barnes-Hut simulation");
+    if (bytes < need)
+        return fail(NB_ERR_ARG, "nb_debug_read: buffer too small");
+    if (need)
+        NB_HIP(hipMemcpy(out, src, need, hipMemcpyDeviceToHost));
+    if (written)
+        *written = need;
+    return NB_OK;
+}
+
+}  // extern "C"

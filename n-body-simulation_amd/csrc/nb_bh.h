@@ -1,0 +1,73 @@
+// nb_bh.h -- Barnes-Hut pipeline of libnbody_hip.so (internal).
+//
+// Stage by stage it replaces the reference's GPU kernels
+//   ResetKernel / ComputeBoundingBoxKernel / ConstructQuadTreeKernel / ComputeForceKernel
+//   (src/gpu/BH/barnesHut_kernel.cu:34-444)
+// while reproducing the accept/reject decisions of the CPU tree
+//   BarnesHut / QuadTree (src/cpu/barnesHut.cpp:23-144, src/cpu/quadtree.cpp:41-237):
+// one body per leaf, unbounded depth (31 levels here), rectangular midpoint cells.
+#pragma once
+
+#include "nb_common.h"
+
+namespace nb {
+
+constexpr int BH_KEY_LEVELS = 31;  // 2 bits per level in a 62-bit key
+constexpr int BH_MAX_DEPTH = 34;   // tree levels the build loops over (31 cell levels, leaves, spare)
+constexpr int BH_SCAN_BLOCKS = 512;
+
+struct BhBuffers {
+    int n = 0;
+    size_t node_cap = 0;
+    double *box = nullptr;        // tl.x, tl.y, br.x, br.y (float-rounded values held in doubles)
+    double *bbox_part = nullptr;  // per-block partial min/max
+    uint64_t *keys[2] = {nullptr, nullptr};
+    uint32_t *idx[2] = {nullptr, nullptr};
+    int sorted = 0;               // which of the two holds the sorted result
+    uint32_t *hist = nullptr;     // 256 x sort blocks
+    int sort_blocks = 0;
+    float4 *posm_s = nullptr;     // per sorted body {x, y, m, radius} in internal units
+    uint4 *node_meta = nullptr;   // first body, body count, first child, child count | cell level << 8
+    uint4 *split = nullptr;       // per frontier slot: the three quadrant boundaries and child count
+    uint32_t *level_start = nullptr;  // BH_MAX_DEPTH + 2 entries
+    uint32_t *bsum = nullptr;     // BH_SCAN_BLOCKS block sums
+    double *node_com = nullptr;   // 4 doubles per node: com.x, com.y, mass, cell x-width (0 = leaf)
+    float4 *node_rec = nullptr;   // traversal record {com.x, com.y, mass, w}: w = (width/theta)^2 for a
+                                  // cell, -(radius + collision_th) for a leaf, internal units
+    uint2 *node_child = nullptr;  // first child, child count
+    uint32_t *tlist = nullptr;    // sorted positions of this rank's targets (multi-GPU), else unused
+    uint32_t *tcount = nullptr;   // 1 entry: number of targets in tlist
+    unsigned long long *counters = nullptr;  // 8 statistics words
+};
+
+int bh_alloc(BhBuffers &b, int n);
+void bh_free(BhBuffers &b);
+
+struct BhStepArgs {
+    const double2 *pos;
+    const double *mass;
+    const double *radius;
+    const uint8_t *dyn;
+    double2 *vel;
+    double2 *acc;
+    double2 *pos_out;  // same array as pos (integration is in place)
+    int n;
+    int t0, t1;        // exchange-order index range of the bodies this rank integrates
+    Units units;
+    ForceConsts fc;
+    IntegrateArgs ia;
+    double theta;
+    double bbox_margin;
+    double collision_th;
+    int collect_stats;
+};
+
+// Individual stages (also driven one by one by the stage tests through nb_step).
+int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
+int bh_keys(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
+int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
+int bh_build(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
+int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
+int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
+
+}  // namespace nb

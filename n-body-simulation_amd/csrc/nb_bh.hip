@@ -1,0 +1,897 @@
+// nb_bh.hip -- Barnes-Hut pipeline for gfx950 (see nb_bh.h for what it replaces).
+//
+// Stages of one step, all on one stream, no host synchronisation in between:
+//   1 bbox     per-block min/max by wave shuffles, one finishing block; the box is rounded to
+//              float and padded as BarnesHut::computeBoundingBox does (barnesHut.cpp:23-35)
+//   2 keys     62-bit quadrant paths by the reference's own FP64 midpoint descent
+//              (quadtree.cpp:41-72,107-143), so ties and rounding fall where they fall there
+//   3 sort     stable LSD radix sort of (key, index), 8 bits per pass
+//   4 build    quadtree of the cells that hold >= 2 bodies in >= 2 quadrants, level by level:
+//              children of a node are contiguous, a node's quadrant boundaries come from
+//              binary searches in the sorted keys.  Chains of single-child cells of the
+//              reference tree are not stored: they share their descendant's centre of mass and
+//              a wider cell, so the opening test passes for the chain iff it passes for its
+//              smallest cell, with the same force.
+//   5 com      bottom-up centre of mass, FP64, children summed in the reference's order
+//              TL,TR,BL,BR (quadtree.cpp:187-228)
+//   6 force    one wave per 64 Morton-consecutive bodies; the wave shares a stack of
+//              (node, lane mask) entries in LDS, fetches up to 64 nodes per round trip, and
+//              every lane applies its OWN opening test (barnesHut.cpp:70-71), so each body
+//              accepts exactly the cells the reference accepts for it.  Integration
+//              (barnesHut.cpp:108-123) is fused into the epilogue.
+#include "nb_bh.h"
+
+namespace nb {
+
+// ------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Exclusive scan of one int per thread over a 256-thread block; total = block sum.
+__device__ __forceinline__ int block_excl_scan_256(int v, int &total)
+{
+    __shared__ int wsum[4];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if (lane >= o)
+            incl += t;
+    }
+    __syncthreads();  // protects wsum against the previous call's readers
+    if (lane == 63)
+        wsum[w] = incl;
+    __syncthreads();
+    int base = 0;
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int s = wsum[k];
+        if (k < w)
+            base += s;
+        tot += s;
+    }
+    total = tot;
+    return base + incl - v;
+}
+
+__device__ __forceinline__ int block_sum_256(int v)
+{
+    __shared__ int wsum2[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lane_id() == 0)
+        wsum2[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3];
+}
+
+// ------------------------------------------------------------------ 1 bounding box
+
+constexpr int BBOX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void k_bbox_partial(const double2 *pos, int n, double *part)
+{
+    double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        double2 p = pos[i];
+        mnx = fmin(mnx, p.x);
+        mxx = fmax(mxx, p.x);
+        mny = fmin(mny, p.y);
+        mxy = fmax(mxy, p.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fmin(mnx, __shfl_xor(mnx, o));
+        mxx = fmax(mxx, __shfl_xor(mxx, o));
+        mny = fmin(mny, __shfl_xor(mny, o));
+        mxy = fmax(mxy, __shfl_xor(mxy, o));
+    }
+    __shared__ double sh[4][4];
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+        sh[w][0] = mnx;
+        sh[w][1] = mxx;
+        sh[w][2] = mny;
+        sh[w][3] = mxy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            mnx = fmin(mnx, sh[k][0]);
+            mxx = fmax(mxx, sh[k][1]);
+            mny = fmin(mny, sh[k][2]);
+            mxy = fmax(mxy, sh[k][3]);
+        }
+        double *o = part + 4 * blockIdx.x;
+        o[0] = mnx;
+        o[1] = mxx;
+        o[2] = mny;
+        o[3] = mxy;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk, double margin, double *box)
+{
+    double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        mnx = fmin(mnx, part[4 * i + 0]);
+        mxx = fmax(mxx, part[4 * i + 1]);
+        mny = fmin(mny, part[4 * i + 2]);
+        mxy = fmax(mxy, part[4 * i + 3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fmin(mnx, __shfl_xor(mnx, o));
+        mxx = fmax(mxx, __shfl_xor(mxx, o));
+        mny = fmin(mny, __shfl_xor(mny, o));
+        mxy = fmax(mxy, __shfl_xor(mxy, o));
+    }
+    __shared__ double sh[4][4];
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+        sh[w][0] = mnx;
+        sh[w][1] = mxx;
+        sh[w][2] = mny;
+        sh[w][3] = mxy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            mnx = fmin(mnx, sh[k][0]);
+            mxx = fmax(mxx, sh[k][1]);
+            mny = fmin(mny, sh[k][2]);
+            mxy = fmax(mxy, sh[k][3]);
+        }
+        // fminf/fmaxf of the reference round every candidate to float (barnesHut.cpp:28-31);
+        // rounding is monotone, so rounding the extreme gives the same box.
+        box[0] = (double)(float)(mnx - margin);  // topLeft.x
+        box[1] = (double)(float)(mxy + margin);  // topLeft.y
+        box[2] = (double)(float)(mxx + margin);  // botRight.x
+        box[3] = (double)(float)(mny - margin);  // botRight.y
+    }
+}
+
+int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+{
+    int blocks = (a.n + 255) / 256;
+    if (blocks > BBOX_BLOCKS)
+        blocks = BBOX_BLOCKS;
+    hipLaunchKernelGGL(k_bbox_partial, dim3(blocks), dim3(256), 0, s, a.pos, a.n, b.bbox_part);
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, b.box);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------ 2 keys
+
+// Digit of level l (0 = the root's split) occupies bits [61-2l, 60-2l]:
+// 2*(below the y midpoint) + (right of the x midpoint), i.e. TL=0, TR=1, BL=2, BR=3.
+__global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const double *box, uint64_t *keys,
+                                              uint32_t *idx)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    double tlx = box[0], tly = box[1], brx = box[2], bry = box[3];
+    const double2 p = pos[i];
+    uint64_t k = 0;
+#pragma unroll 1
+    for (int l = 0; l < BH_KEY_LEVELS; ++l) {
+        const double mx = (tlx + brx) / 2.0, my = (tly + bry) / 2.0;
+        const bool right = !(mx >= p.x);  // getQuadrant: mid >= x is the left half
+        const bool below = !(my <= p.y);  // mid <= y is the top half
+        tlx = right ? mx : tlx;
+        brx = right ? brx : mx;
+        tly = below ? my : tly;
+        bry = below ? bry : my;
+        k = (k << 2) | ((uint64_t)below << 1) | (uint64_t)right;
+    }
+    keys[i] = k;
+    idx[i] = (uint32_t)i;
+}
+
+int bh_keys(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+{
+    hipLaunchKernelGGL(k_keys, dim3((a.n + 255) / 256), dim3(256), 0, s, a.pos, a.n, b.box, b.keys[0], b.idx[0]);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------ 3 radix sort
+
+constexpr int SORT_ITEMS = 8;
+constexpr int SORT_TILE = 256 * SORT_ITEMS;
+constexpr int SORT_BITS = 8;
+constexpr int SORT_BINS = 1 << SORT_BITS;
+constexpr int KEY_BITS = 2 * BH_KEY_LEVELS;
+
+__global__ __launch_bounds__(256) void k_sort_count(const uint64_t *keys, int n, int shift, uint32_t *hist, int nblk)
+{
+    __shared__ uint32_t h[SORT_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        int i = base + it * 256 + threadIdx.x;
+        if (i < n)
+            atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (SORT_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// Exclusive scan of `count` uint32 in place, one 1024-thread block.
+__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *data, int count)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_sh;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (count + 1023) / 1024;
+    const int beg = tid * per;
+    int end = beg + per;
+    if (end > count)
+        end = count;
+    uint32_t sum = 0;
+    for (int i = beg; i < end; ++i)
+        sum += data[i];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o);
+        if (lane >= o)
+            incl += t;
+    }
+    if (lane == 63)
+        wsum[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = 0; k < w; ++k)
+        base += wsum[k];
+    uint32_t run = base + incl - sum;
+    for (int i = beg; i < end; ++i) {
+        uint32_t v = data[i];
+        data[i] = run;
+        run += v;
+    }
+    (void)carry_sh;
+}
+
+// Stable scatter of one 8-bit digit.  Wave w of a block owns a contiguous chunk of
+// 64*SORT_ITEMS keys and ranks them sub-round by sub-round against its own LDS counters
+// (no block barrier inside), so the order inside a digit is the input order.
+__global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, const uint32_t *idx_in,
+                                                      uint64_t *keys_out, uint32_t *idx_out, int n, int shift,
+                                                      const uint32_t *hist, int nblk)
+{
+    __shared__ uint32_t wcnt[4][SORT_BINS];
+    __shared__ uint32_t dbase[SORT_BINS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        wcnt[k][tid] = 0;
+    __syncthreads();
+
+    const int chunk = blockIdx.x * SORT_TILE + w * (64 * SORT_ITEMS);
+    uint64_t key[SORT_ITEMS];
+    uint32_t val[SORT_ITEMS];
+    uint32_t rank[SORT_ITEMS];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    volatile uint32_t *mycnt = wcnt[w];
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const int i = chunk + it * 64 + lane;
+        const bool valid = i < n;
+        key[it] = valid ? keys_in[i] : ~0ull;
+        val[it] = valid ? idx_in[i] : 0u;
+        const uint32_t d = (uint32_t)(key[it] >> shift) & (SORT_BINS - 1);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < SORT_BITS; ++bit) {
+            const bool one = (d >> bit) & 1u;
+            const uint64_t bal = __ballot(one);
+            peers &= one ? bal : ~bal;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t cnt = (uint32_t)__popcll(peers);
+        uint32_t prev = 0;
+        if (valid)
+            prev = mycnt[d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0)
+            mycnt[d] = prev + cnt;
+        __builtin_amdgcn_wave_barrier();
+        rank[it] = prev + before;
+    }
+    __syncthreads();
+    {
+        // thread = digit: exclusive prefix over the four waves, plus this block's global base
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t c = wcnt[k][tid];
+            wcnt[k][tid] = run;
+            run += c;
+        }
+        dbase[tid] = hist[(size_t)tid * nblk + blockIdx.x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const int i = chunk + it * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(key[it] >> shift) & (SORT_BINS - 1);
+            const uint32_t dst = dbase[d] + wcnt[w][d] + rank[it];
+            keys_out[dst] = key[it];
+            idx_out[dst] = val[it];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_sorted(const uint32_t *idx, int n, const double2 *pos,
+                                                       const double *mass, const double *radius, double inv_len,
+                                                       double inv_mass, float4 *posm_s)
+{
+    int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n)
+        return;
+    const uint32_t o = idx[k];
+    const double2 p = pos[o];
+    posm_s[k] = make_float4((float)(p.x * inv_len), (float)(p.y * inv_len), (float)(mass[o] * inv_mass),
+                            (float)(radius[o] * inv_len));
+}
+
+int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+{
+    const int n = a.n;
+    const int nblk = b.sort_blocks;
+    int cur = 0;
+    for (int shift = 0; shift < KEY_BITS; shift += SORT_BITS) {
+        hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, s, b.keys[cur], n, shift, b.hist, nblk);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, b.hist, SORT_BINS * nblk);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, s, b.keys[cur], b.idx[cur], b.keys[cur ^ 1],
+                           b.idx[cur ^ 1], n, shift, b.hist, nblk);
+        cur ^= 1;
+    }
+    b.sorted = cur;
+    hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, s, b.idx[cur], n, a.pos, a.mass, a.radius,
+                       1.0 / a.units.len_unit, 1.0 / a.units.mass_unit, b.posm_s);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------ 4 tree build
+
+__global__ void k_build_init(uint4 *node_meta, uint32_t *level_start, int n, unsigned long long *counters)
+{
+    int t = threadIdx.x;
+    if (t < BH_MAX_DEPTH + 2)
+        level_start[t] = t == 0 ? 0u : 1u;
+    if (t == 0)
+        node_meta[0] = make_uint4(0u, (uint32_t)n, 0u, 0u);
+    if (t < 8)
+        counters[t] = 0ull;
+}
+
+// Slots of tree level d are dealt to the BH_SCAN_BLOCKS blocks in contiguous chunks that are
+// multiples of 256, the same way in the count and in the emit kernel.
+__device__ __forceinline__ void level_chunk(const uint32_t *level_start, int d, uint32_t &lbeg, uint32_t &m,
+                                            uint32_t &cbeg, uint32_t &cend)
+{
+    lbeg = level_start[d];
+    m = level_start[d + 1] - lbeg;
+    uint32_t chunk = (m + BH_SCAN_BLOCKS - 1) / BH_SCAN_BLOCKS;
+    chunk = (chunk + 255u) & ~255u;
+    cbeg = blockIdx.x * chunk;
+    cend = cbeg + chunk;
+    if (cbeg > m)
+        cbeg = m;
+    if (cend > m)
+        cend = m;
+}
+
+// First index in [lo, hi) whose digit at `shift` is >= c (digits are non-decreasing there).
+__device__ __forceinline__ uint32_t digit_lower_bound(const uint64_t *keys, uint32_t lo, uint32_t hi, int shift,
+                                                      uint32_t c)
+{
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (((uint32_t)(keys[mid] >> shift) & 3u) < c)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4 *node_meta, uint4 *split,
+                                                     const uint32_t *level_start, uint32_t *bsum, int d)
+{
+    uint32_t lbeg, m, cbeg, cend;
+    level_chunk(level_start, d, lbeg, m, cbeg, cend);
+    int local = 0;
+    for (uint32_t slot = cbeg + threadIdx.x; slot < cend; slot += 256) {
+        const uint4 meta = node_meta[lbeg + slot];
+        const uint32_t first = meta.x, count = meta.y, last = first + count - 1;
+        uint4 sp = make_uint4(0u, 0u, 0u, 0u);
+        const uint64_t kf = keys[first], kl = keys[last];
+        if (count > 1 && kf != kl) {
+            // level of the smallest cell holding the whole range: the first differing digit
+            const int lvl = (__clzll((long long)(kf ^ kl)) - 2) >> 1;
+            const int shift = KEY_BITS - 2 - 2 * lvl;
+            const uint32_t end = first + count;
+            const uint32_t s1 = digit_lower_bound(keys, first, end, shift, 1u);
+            const uint32_t s2 = digit_lower_bound(keys, s1, end, shift, 2u);
+            const uint32_t s3 = digit_lower_bound(keys, s2, end, shift, 3u);
+            const uint32_t nchild = (s1 > first) + (s2 > s1) + (s3 > s2) + (end > s3);
+            sp = make_uint4(s1, s2, s3, nchild | ((uint32_t)lvl << 8));
+            local += (int)nchild;
+        }
+        split[slot] = sp;
+    }
+    const int tot = block_sum_256(local);
+    if (threadIdx.x == 0)
+        bsum[blockIdx.x] = (uint32_t)tot;
+}
+
+__global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, uint2 *node_child, const uint4 *split,
+                                                    uint32_t *level_start, const uint32_t *bsum, int d)
+{
+    uint32_t lbeg, m, cbeg, cend;
+    level_chunk(level_start, d, lbeg, m, cbeg, cend);
+    // children allocated by the blocks before this one, and by the whole level
+    int before = 0, all = 0;
+    for (int k = threadIdx.x; k < BH_SCAN_BLOCKS; k += 256) {
+        int v = (int)bsum[k];
+        all += v;
+        if (k < (int)blockIdx.x)
+            before += v;
+    }
+    before = block_sum_256(before);
+    all = block_sum_256(all);
+    const uint32_t next_beg = level_start[d + 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        level_start[d + 2] = next_beg + (uint32_t)all;
+    uint32_t running = next_beg + (uint32_t)before;
+    for (uint32_t tile = cbeg; tile < cend; tile += 256) {
+        const uint32_t slot = tile + threadIdx.x;
+        const bool valid = slot < cend;
+        uint4 sp = make_uint4(0u, 0u, 0u, 0u);
+        if (valid)
+            sp = split[slot];
+        const int nchild = (int)(sp.w & 0xffu);
+        int tile_total;
+        const int excl = block_excl_scan_256(nchild, tile_total);
+        if (valid) {
+            const uint32_t u = lbeg + slot;
+            uint4 meta = node_meta[u];
+            const uint32_t cf = running + (uint32_t)excl;
+            meta.z = cf;
+            meta.w = sp.w;
+            node_meta[u] = meta;
+            node_child[u] = make_uint2(cf, (uint32_t)nchild);
+            if (nchild) {
+                const uint32_t first = meta.x, end = meta.x + meta.y;
+                const uint32_t b0 = first, b1 = sp.x, b2 = sp.y, b3 = sp.z;
+                uint32_t c = cf;
+                if (b1 > b0)
+                    node_meta[c++] = make_uint4(b0, b1 - b0, 0u, 0u);
+                if (b2 > b1)
+                    node_meta[c++] = make_uint4(b1, b2 - b1, 0u, 0u);
+                if (b3 > b2)
+                    node_meta[c++] = make_uint4(b2, b3 - b2, 0u, 0u);
+                if (end > b3)
+                    node_meta[c++] = make_uint4(b3, end - b3, 0u, 0u);
+            }
+        }
+        running += (uint32_t)tile_total;
+    }
+}
+
+int bh_build(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+{
+    const uint64_t *keys = b.keys[b.sorted];
+    hipLaunchKernelGGL(k_build_init, dim3(1), dim3(64), 0, s, b.node_meta, b.level_start, a.n, b.counters);
+    for (int d = 0; d < BH_MAX_DEPTH - 2; ++d) {
+        hipLaunchKernelGGL(k_build_count, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, keys, b.node_meta, b.split,
+                           b.level_start, b.bsum, d);
+        hipLaunchKernelGGL(k_build_emit, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, b.node_meta, b.node_child, b.split,
+                           b.level_start, b.bsum, d);
+    }
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------ 5 centre of mass
+
+struct ComArgs {
+    const uint4 *node_meta;
+    const uint32_t *level_start;
+    const uint32_t *idx;
+    const double2 *pos;
+    const double *mass;
+    const double *radius;
+    const float4 *posm_s;
+    const double *box;
+    double *node_com;
+    float4 *node_rec;
+    double inv_len, inv_mass, theta, cth;
+};
+
+__global__ __launch_bounds__(256) void k_com(ComArgs a, int d)
+{
+    const uint32_t lbeg = a.level_start[d], lend = a.level_start[d + 1];
+    const double width0 = a.box[2] - a.box[0];  // QuadTree::getWidth of the root (quadtree.cpp:234-237)
+    for (uint32_t u = lbeg + blockIdx.x * 256 + threadIdx.x; u < lend; u += gridDim.x * 256) {
+        const uint4 meta = a.node_meta[u];
+        const uint32_t nchild = meta.w & 0xffu;
+        double cx, cy, mtot, width;
+        float4 rec;
+        if (nchild == 0) {
+            // a leaf: one body, or several bodies with the same 62-bit path taken as one
+            const uint32_t first = meta.x, count = meta.y;
+            if (count == 1) {
+                const uint32_t o = a.idx[first];
+                const double2 p = a.pos[o];
+                cx = p.x;
+                cy = p.y;
+                mtot = a.mass[o];
+                const float4 pm = a.posm_s[first];
+                rec = make_float4(pm.x, pm.y, pm.z, -(float)((a.radius[o] + a.cth) * a.inv_len));
+            } else {
+                double sx = 0.0, sy = 0.0, rmax = 0.0;
+                mtot = 0.0;
+                for (uint32_t k = first; k < first + count; ++k) {
+                    const uint32_t o = a.idx[k];
+                    const double2 p = a.pos[o];
+                    const double mk = a.mass[o];
+                    mtot += mk;
+                    sx += p.x * mk;
+                    sy += p.y * mk;
+                    rmax = fmax(rmax, a.radius[o]);
+                }
+                cx = sx / mtot;
+                cy = sy / mtot;
+                rec = make_float4((float)(cx * a.inv_len), (float)(cy * a.inv_len), (float)(mtot * a.inv_mass),
+                                  -(float)((rmax + a.cth) * a.inv_len));
+            }
+            width = 0.0;
+        } else {
+            // updateCenterMass: total = sum of child masses, com = sum(child com * child mass) / total,
+            // children in the order TL,TR,BL,BR = ascending digit
+            const uint32_t cf = meta.z;
+            double sx = 0.0, sy = 0.0;
+            mtot = 0.0;
+            for (uint32_t c = cf; c < cf + nchild; ++c) {
+                const double ccx = a.node_com[4 * (size_t)c + 0];
+                const double ccy = a.node_com[4 * (size_t)c + 1];
+                const double cm = a.node_com[4 * (size_t)c + 2];
+                mtot += cm;
+                sx += ccx * cm;
+                sy += ccy * cm;
+            }
+            cx = sx / mtot;
+            cy = sy / mtot;
+            const int lvl = (int)(meta.w >> 8);
+            width = ldexp(width0, -lvl);
+            const double wt = width * a.inv_len / a.theta;  // width / dist < theta  <=>  dist > width / theta
+            rec = make_float4((float)(cx * a.inv_len), (float)(cy * a.inv_len), (float)(mtot * a.inv_mass),
+                              (float)(wt * wt));
+        }
+        double *o = a.node_com + 4 * (size_t)u;
+        o[0] = cx;
+        o[1] = cy;
+        o[2] = mtot;
+        o[3] = width;
+        a.node_rec[u] = rec;
+    }
+}
+
+int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+{
+    ComArgs c;
+    c.node_meta = b.node_meta;
+    c.level_start = b.level_start;
+    c.idx = b.idx[b.sorted];
+    c.pos = a.pos;
+    c.mass = a.mass;
+    c.radius = a.radius;
+    c.posm_s = b.posm_s;
+    c.box = b.box;
+    c.node_com = b.node_com;
+    c.node_rec = b.node_rec;
+    c.inv_len = 1.0 / a.units.len_unit;
+    c.inv_mass = 1.0 / a.units.mass_unit;
+    c.theta = a.theta;
+    c.cth = a.collision_th;
+    for (int d = BH_MAX_DEPTH - 2; d >= 0; --d)
+        hipLaunchKernelGGL(k_com, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, c, d);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------ 6 traversal + integration
+
+constexpr int TR_STACK = 512;             // entries per wave
+constexpr int TR_HIGH = TR_STACK - 100;   // above this the wave pops one node at a time: a
+                                          // depth-first descent adds at most 3 entries per tree
+                                          // level (< 32 levels), so the stack cannot overflow
+
+struct ForceArgs {
+    const float4 *posm_s;
+    const float4 *node_rec;
+    const uint2 *node_child;
+    const uint32_t *idx;
+    const uint32_t *tlist;   // may be null: targets are all sorted bodies
+    const uint32_t *tcount;  // device count of tlist entries (when tlist != null)
+    const uint8_t *dyn;
+    double2 *pos;
+    double2 *vel;
+    double2 *acc;
+    unsigned long long *counters;
+    int n;
+    ForceConsts fc;
+    IntegrateArgs ia;
+};
+
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <bool EXACT, bool STATS>
+__global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
+{
+    __shared__ uint32_t st_node[4][TR_STACK];
+    __shared__ uint64_t st_mask[4][TR_STACK];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    uint32_t *snode = st_node[w];
+    uint64_t *smask = st_mask[w];
+
+    const int ntarget = a.tlist ? (int)*a.tcount : a.n;
+    const int slot = (blockIdx.x * 4 + w) * 64 + lane;
+    const bool valid = slot < ntarget;
+    if ((blockIdx.x * 4 + w) * 64 >= ntarget)
+        return;  // whole wave idle (no block barriers below)
+    const int k = valid ? (a.tlist ? (int)a.tlist[slot] : slot) : 0;
+    const uint32_t body = a.idx[k];
+    const float4 me = a.posm_s[k];
+    const float xi = me.x, yi = me.y, ri = me.w;
+    const bool dynamic = valid && a.dyn[body];
+    // BarnesHut::isCollide(Body, Vector): 2 r_i + th > dist drops an accepted cell (barnesHut.cpp:131-134)
+    const float thn = 2.f * ri + a.fc.cth;
+    const float thn2 = thn * thn;
+    const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
+
+    double sx = 0.0, sy = 0.0;
+    unsigned long long n_eval = 0, n_acc = 0;
+
+    int top = 0;
+    {
+        const uint64_t m0 = __ballot(dynamic);
+        if (m0 != 0ull) {
+            if (lane == 0) {
+                snode[0] = 0u;
+                smask[0] = m0;
+            }
+            top = 1;
+        }
+    }
+    while (top > 0) {
+        int c = top < 64 ? top : 64;
+        int room = (TR_HIGH - top) / 3;
+        if (room < 1)
+            room = 1;
+        if (c > room)
+            c = room;
+        const int base = top - c;
+        uint32_t u = 0;
+        uint64_t um = 0ull;
+        if (lane < c) {
+            u = snode[base + lane];
+            um = smask[base + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 ch = make_uint2(0u, 0u);
+        if (lane < c) {
+            rec = a.node_rec[u];
+            ch = a.node_child[u];
+        }
+        top = base;
+        float fx = 0.f, fy = 0.f;
+        for (int j = 0; j < c; ++j) {
+            const float nx = readlane_f(rec.x, j);
+            const float ny = readlane_f(rec.y, j);
+            const float nm = readlane_f(rec.z, j);
+            const float nw = readlane_f(rec.w, j);
+            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)um, j);
+            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(um >> 32), j);
+            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
+            const bool act = (mj >> lane) & 1ull;
+            const float dx = nx - xi, dy = ny - yi;
+            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+            const float r2 = d2 + eps2;
+            bool ok;
+            if (__float_as_uint(nw) & 0x80000000u) {
+                // a body: skipped when r_i + r_j + th > dist, or when it is the body itself
+                // (barnesHut.cpp:59); the body itself has d2 == 0
+                const float th = ri - nw;
+                ok = act && d2 >= th * th && d2 > 0.f;
+            } else {
+                // a cell: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened
+                const bool accept = d2 > nw;
+                ok = act && accept && d2 >= thn2;
+                const uint64_t om = __ballot(act && !accept);
+                if (om != 0ull) {
+                    const int cf = __builtin_amdgcn_readlane((int)ch.x, j);
+                    const int nc = __builtin_amdgcn_readlane((int)ch.y, j);
+                    if (lane < nc) {
+                        snode[top + lane] = (uint32_t)(cf + lane);
+                        smask[top + lane] = om;
+                    }
+                    top += nc;
+                }
+            }
+            float s;
+            if (EXACT) {
+                const float r3 = r2 * __builtin_sqrtf(r2);
+                s = nm * __builtin_amdgcn_rcpf(r3 + eps3);
+            } else {
+                const float rinv = __builtin_amdgcn_rsqf(r2);
+                s = (nm * rinv) * (rinv * rinv);
+            }
+            s = ok ? s : 0.f;
+            fx = __builtin_fmaf(dx, s, fx);
+            fy = __builtin_fmaf(dy, s, fy);
+            if (STATS) {
+                n_eval += (unsigned long long)__popcll(mj);
+                n_acc += (unsigned long long)__popcll(__ballot(ok));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        sx += (double)fx;
+        sy += (double)fy;
+    }
+
+    if (STATS && lane == 0) {
+        atomicAdd(&a.counters[0], n_eval);
+        atomicAdd(&a.counters[1], n_acc);
+    }
+    if (!valid)
+        return;
+    double ax = 0.0, ay = 0.0;
+    if (dynamic) {
+        ax = sx * a.ia.acc_factor;
+        ay = sy * a.ia.acc_factor;
+        a.acc[body] = make_double2(ax, ay);
+    }
+    // a static body keeps the acceleration it was given (calculateAcceleration, barnesHut.cpp:96-106)
+    // and every body is advanced with its own velocity (barnesHut.cpp:108-123)
+    if (a.ia.do_integrate) {
+        const double2 aa = dynamic ? make_double2(ax, ay) : a.acc[body];
+        double2 v = a.vel[body];
+        double2 p = a.pos[body];
+        v.x += aa.x * a.ia.dt;
+        v.y += aa.y * a.ia.dt;
+        p.x += v.x * a.ia.dt;
+        p.y += v.y * a.ia.dt;
+        a.vel[body] = v;
+        a.pos[body] = p;
+    }
+}
+
+__global__ void k_bh_finish_counters(const uint32_t *level_start, unsigned long long *counters)
+{
+    if (threadIdx.x == 0) {
+        int levels = 0;
+        for (int d = 0; d < BH_MAX_DEPTH; ++d)
+            if (level_start[d + 1] > level_start[d])
+                levels = d + 1;
+        counters[2] = level_start[levels];
+        counters[3] = (unsigned long long)levels;
+    }
+}
+
+int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+{
+    ForceArgs f;
+    f.posm_s = b.posm_s;
+    f.node_rec = b.node_rec;
+    f.node_child = b.node_child;
+    f.idx = b.idx[b.sorted];
+    f.tlist = nullptr;
+    f.tcount = nullptr;
+    f.dyn = a.dyn;
+    f.pos = a.pos_out;
+    f.vel = a.vel;
+    f.acc = a.acc;
+    f.counters = b.counters;
+    f.n = a.n;
+    f.fc = a.fc;
+    f.ia = a.ia;
+    const int waves = (a.n + 63) / 64;
+    dim3 grid((waves + 3) / 4);
+    if (a.collect_stats) {
+        if (a.fc.exact_denom)
+            hipLaunchKernelGGL((k_bh_force<true, true>), grid, dim3(256), 0, s, f);
+        else
+            hipLaunchKernelGGL((k_bh_force<false, true>), grid, dim3(256), 0, s, f);
+        hipLaunchKernelGGL(k_bh_finish_counters, dim3(1), dim3(64), 0, s, b.level_start, b.counters);
+    } else {
+        if (a.fc.exact_denom)
+            hipLaunchKernelGGL((k_bh_force<true, false>), grid, dim3(256), 0, s, f);
+        else
+            hipLaunchKernelGGL((k_bh_force<false, false>), grid, dim3(256), 0, s, f);
+    }
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------ buffers
+
+template <typename T>
+static int dev_alloc(T *&p, size_t count)
+{
+    void *v = nullptr;
+    hipError_t e = hipMalloc(&v, count * sizeof(T) + 256);
+    if (e != hipSuccess)
+        return fail(NB_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    p = (T *)v;
+    return NB_OK;
+}
+
+int bh_alloc(BhBuffers &b, int n)
+{
+    b.n = n;
+    b.node_cap = 2 * (size_t)n + 8;
+    b.sort_blocks = (n + SORT_TILE - 1) / SORT_TILE;
+    NB_TRY(dev_alloc(b.box, 4));
+    NB_TRY(dev_alloc(b.bbox_part, 4 * BBOX_BLOCKS));
+    for (int k = 0; k < 2; ++k) {
+        NB_TRY(dev_alloc(b.keys[k], (size_t)n));
+        NB_TRY(dev_alloc(b.idx[k], (size_t)n));
+    }
+    NB_TRY(dev_alloc(b.hist, (size_t)SORT_BINS * b.sort_blocks));
+    NB_TRY(dev_alloc(b.posm_s, (size_t)n));
+    NB_TRY(dev_alloc(b.node_meta, b.node_cap));
+    NB_TRY(dev_alloc(b.split, (size_t)n + 256));
+    NB_TRY(dev_alloc(b.level_start, BH_MAX_DEPTH + 2));
+    NB_TRY(dev_alloc(b.bsum, BH_SCAN_BLOCKS));
+    NB_TRY(dev_alloc(b.node_com, 4 * b.node_cap));
+    NB_TRY(dev_alloc(b.node_rec, b.node_cap));
+    NB_TRY(dev_alloc(b.node_child, b.node_cap));
+    NB_TRY(dev_alloc(b.tlist, (size_t)n));
+    NB_TRY(dev_alloc(b.tcount, 4));
+    NB_TRY(dev_alloc(b.counters, 8));
+    return NB_OK;
+}
+
+void bh_free(BhBuffers &b)
+{
+    (void)hipFree(b.box);
+    (void)hipFree(b.bbox_part);
+    for (int k = 0; k < 2; ++k) {
+        (void)hipFree(b.keys[k]);
+        (void)hipFree(b.idx[k]);
+    }
+    (void)hipFree(b.hist);
+    (void)hipFree(b.posm_s);
+    (void)hipFree(b.node_meta);
+    (void)hipFree(b.split);
+    (void)hipFree(b.level_start);
+    (void)hipFree(b.bsum);
+    (void)hipFree(b.node_com);
+    (void)hipFree(b.node_rec);
+    (void)hipFree(b.node_child);
+    (void)hipFree(b.tlist);
+    (void)hipFree(b.tcount);
+    (void)hipFree(b.counters);
+    b = BhBuffers();
+}
+
+}  // namespace nb

@@ -1,0 +1,72 @@
+// nb_common.h -- internal declarations shared by the HIP sources of libnbody_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "nbody.h"
+
+namespace nb {
+
+// ---- error plumbing (the reference prints and exits, src/gpu/BH/err.h:21-46; here every
+// failure becomes a status code plus a thread-local message) ----
+void set_error(const std::string &msg);
+int fail(int status, const std::string &msg);
+
+#define NB_HIP(call)                                                                            \
+    do {                                                                                        \
+        hipError_t nb_e_ = (call);                                                              \
+        if (nb_e_ != hipSuccess)                                                                \
+            return ::nb::fail(NB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(nb_e_) + \
+                                              " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+#define NB_TRY(call)            \
+    do {                        \
+        int nb_rc_ = (call);    \
+        if (nb_rc_ != NB_OK)    \
+            return nb_rc_;      \
+    } while (0)
+
+// ---- internal units ----
+// Lengths are divided by len_unit and masses by mass_unit, both powers of two, before they
+// are rounded to float: scaling by a power of two is exact, and it keeps r^3 and m/r^3 of
+// astronomical SI values (1e36, 1e-12) far from the float range limits.
+struct Units {
+    double len_unit;    // metres per internal length unit (2^k)
+    double mass_unit;   // kilograms per internal mass unit (2^k)
+    double acc_factor;  // multiply sum(m' d' / r'^3) by this to get m/s^2: G mass_unit / len_unit^2
+};
+
+// Scalars every force kernel needs, in internal units.
+struct ForceConsts {
+    float eps2;      // eps^2 / len_unit^2 (inside the square root)
+    float eps3;      // eps^2 / len_unit^3 (the reference adds eps^2 to r^3)
+    float cth;       // collision_th / len_unit
+    int exact_denom; // 0: eps3 cannot change r^3 + eps3 in float for any pair outside the cutoff
+};
+
+struct IntegrateArgs {
+    double acc_factor;
+    double dt;
+    double inv_len_unit;
+    int do_integrate;  // 0: only store accelerations
+};
+
+// ---- direct sum (nb_direct.hip) ----
+// posm: {x, y, m, radius + collision_th} per body in internal units (float4), n records.
+// Integrates targets [t0, t0+nt): reads posm_cur, writes pos/vel/acc (double2) and the
+// targets' records of posm_next.  part: scratch of jsplit*nt double2 when jsplit > 1.
+int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const float *rad, int n, int t0, int nt,
+                const ForceConsts &fc, const IntegrateArgs &ia, const uint8_t *dyn, double2 *pos, double2 *vel,
+                double2 *acc, double2 *part, int jsplit);
+int direct_choose_jsplit(int n, int nt);
+
+// pos/mass/radius (double) -> posm records + scaled radius, bodies [i0, i1)
+int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int i0, int i1,
+              double inv_len_unit, double inv_mass_unit, double collision_th, float4 *posm, float *rad);
+
+}  // namespace nb
