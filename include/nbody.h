@@ -153,11 +153,13 @@ enum nb_debug_array {
     NB_DBG_SORTED_IDX = 3,  /* n uint32: exchange-order index of the k-th sorted body */
     NB_DBG_NODE_RANGE = 4,  /* nnodes x 2 uint32: first sorted body, body count */
     NB_DBG_NODE_CHILD = 5,  /* nnodes x 2 uint32: first child node, child count */
-    NB_DBG_NODE_COM = 6,    /* nnodes x 4 doubles: com.x, com.y, mass, cell x-width (0 for a leaf) */
+    NB_DBG_NODE_COM = 6,    /* nnodes x 4 doubles: com.x, com.y, mass, cell x-width; a leaf holds minus its
+                               body's radius there (sign bit set, -0.0 for radius 0) */
     NB_DBG_LEVEL_START = 7, /* 65 uint32: first node of each tree level, then total */
     NB_DBG_ORDER = 8,       /* n uint32: caller index of the body at each exchange-order slot */
     NB_DBG_COUNTERS = 9     /* 8 uint64: [0] body-node evaluations, [1] accepted interactions,
-                               [2] nodes, [3] tree levels, of the last Barnes-Hut step */
+                               [2] nodes, [3] tree levels, [4] node visits re-decided in FP64,
+                               of the last Barnes-Hut step run with stage timing on */
 };
 /* Copies the array into out (bytes = capacity of out); *written gets the size. */
 int nb_debug_read(nb_sim *sim, int which, void *out, size_t bytes, size_t *written);

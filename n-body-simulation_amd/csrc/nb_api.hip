@@ -46,6 +46,7 @@ struct nb_sim {
     // state in exchange order; pos has room for world*chunk records
     size_t cap = 0;
     double2 *pos = nullptr, *vel = nullptr, *acc = nullptr;
+    double2 *pos2 = nullptr;  // direct sum: the other FP64 position buffer (pos is the current one)
     double *mass = nullptr, *radius = nullptr;
     uint8_t *dyn = nullptr;
     float4 *posm[2] = {nullptr, nullptr};
@@ -153,7 +154,8 @@ int step_local(nb_sim *s, int do_integrate)
     if (s->alg == NB_ALG_DIRECT) {
         mark(s, 0);
         NB_TRY(direct_step(s->stream, s->posm[s->cur], s->posm[s->cur ^ 1], s->rad_s, s->n, s->t0, s->t1 - s->t0, s->fc,
-                           integrate_args(s, do_integrate), s->dyn, s->pos, s->vel, s->acc, s->part, s->jsplit));
+                           integrate_args(s, do_integrate), s->dyn, s->pos, s->pos2, s->radius, s->p.collision_th,
+                           s->vel, s->acc, s->part, s->jsplit));
         mark(s, 1);
         return NB_OK;
     }
@@ -180,12 +182,13 @@ int step_finish(nb_sim *s)
         // records of the bodies other ranks advanced come from the gathered positions
         if (s->world > 1) {
             const double il = 1.0 / s->units.len_unit, im = 1.0 / s->units.mass_unit;
-            NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, 0, s->t0, il, im, s->p.collision_th,
+            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, 0, s->t0, il, im, s->p.collision_th,
                              s->posm[s->cur ^ 1], s->rad_s));
-            NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, s->t1, s->n, il, im, s->p.collision_th,
+            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, s->t1, s->n, il, im, s->p.collision_th,
                              s->posm[s->cur ^ 1], s->rad_s));
         }
         s->cur ^= 1;
+        std::swap(s->pos, s->pos2);
     }
     return NB_OK;
 }
@@ -209,6 +212,7 @@ int collect_timing(nb_sim *s)
 void release(nb_sim *s)
 {
     (void)hipFree(s->pos);
+    (void)hipFree(s->pos2);
     (void)hipFree(s->vel);
     (void)hipFree(s->acc);
     (void)hipFree(s->mass);
@@ -278,6 +282,7 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
     chk(dev_alloc(s->radius, s->cap));
     chk(dev_alloc(s->dyn, s->cap));
     if (alg == NB_ALG_DIRECT) {
+        chk(dev_alloc(s->pos2, s->cap));
         chk(dev_alloc(s->posm[0], s->cap));
         chk(dev_alloc(s->posm[1], s->cap));
         chk(dev_alloc(s->rad_s, s->cap));
@@ -492,7 +497,8 @@ int nb_exchange_buffer(nb_sim *s, void **device_ptr, size_t *chunk_records, size
 {
     if (!s || !device_ptr || !chunk_records || !record_bytes)
         return fail(NB_ERR_ARG, "nb_exchange_buffer: NULL argument");
-    *device_ptr = s->pos;
+    // direct sum writes the new positions to the other buffer; mid-step that is the one to gather
+    *device_ptr = (s->alg == NB_ALG_DIRECT && s->mid_step) ? s->pos2 : s->pos;
     *chunk_records = s->chunk;
     *record_bytes = sizeof(double2);
     return NB_OK;

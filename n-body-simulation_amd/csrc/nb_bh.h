@@ -31,7 +31,8 @@ struct BhBuffers {
     uint4 *split = nullptr;       // per frontier slot: the three quadrant boundaries and child count
     uint32_t *level_start = nullptr;  // BH_MAX_DEPTH + 2 entries
     uint32_t *bsum = nullptr;     // BH_SCAN_BLOCKS block sums
-    double *node_com = nullptr;   // 4 doubles per node: com.x, com.y, mass, cell x-width (0 = leaf)
+    double *node_com = nullptr;   // 4 doubles per node: com.x, com.y, mass, and the cell's x-width,
+                                  // or for a leaf minus its body's radius (sign bit set)
     float4 *node_rec = nullptr;   // traversal record {com.x, com.y, mass, w}: w = (width/theta)^2 for a
                                   // cell, -(radius + collision_th) for a leaf, internal units
     uint2 *node_child = nullptr;  // first child, child count

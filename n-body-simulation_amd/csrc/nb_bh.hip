@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void k_com(ComArgs a, int d)
                 mtot = a.mass[o];
                 const float4 pm = a.posm_s[first];
                 rec = make_float4(pm.x, pm.y, pm.z, -(float)((a.radius[o] + a.cth) * a.inv_len));
+                width = -a.radius[o];
             } else {
                 double sx = 0.0, sy = 0.0, rmax = 0.0;
                 mtot = 0.0;
@@ -558,8 +559,8 @@ __global__ __launch_bounds__(256) void k_com(ComArgs a, int d)
                 cy = sy / mtot;
                 rec = make_float4((float)(cx * a.inv_len), (float)(cy * a.inv_len), (float)(mtot * a.inv_mass),
                                   -(float)((rmax + a.cth) * a.inv_len));
+                width = -rmax;
             }
-            width = 0.0;
         } else {
             // updateCenterMass: total = sum of child masses, com = sum(child com * child mass) / total,
             // children in the order TL,TR,BL,BR = ascending digit
@@ -625,10 +626,12 @@ struct ForceArgs {
     const float4 *posm_s;
     const float4 *node_rec;
     const uint2 *node_child;
+    const double *node_com;
     const uint32_t *idx;
     const uint32_t *tlist;   // may be null: targets are all sorted bodies
     const uint32_t *tcount;  // device count of tlist entries (when tlist != null)
     const uint8_t *dyn;
+    const double *radius;
     double2 *pos;
     double2 *vel;
     double2 *acc;
@@ -636,12 +639,20 @@ struct ForceArgs {
     int n;
     ForceConsts fc;
     IntegrateArgs ia;
+    double theta;
+    double collision_th;
 };
 
 __device__ __forceinline__ float readlane_f(float v, int l)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
+
+// A float comparison whose two sides differ by less than this fraction is repeated in FP64
+// on the FP64 positions.  The float distance of two bodies carries the rounding of their
+// coordinates (up to 2^-24 of the domain each), which near the cutoff distance is a few
+// 1e-6 of the distance; the band is several times that.
+constexpr float TR_BAND = 4.0e-5f;
 
 template <bool EXACT, bool STATS>
 __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
@@ -665,10 +676,13 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     // BarnesHut::isCollide(Body, Vector): 2 r_i + th > dist drops an accepted cell (barnesHut.cpp:131-134)
     const float thn = 2.f * ri + a.fc.cth;
     const float thn2 = thn * thn;
+    const float thn2_band = thn2 * TR_BAND;
     const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
+    const double2 pd = a.pos[body];
+    const double rd = a.radius[body];
 
     double sx = 0.0, sy = 0.0;
-    unsigned long long n_eval = 0, n_acc = 0;
+    unsigned long long n_eval = 0, n_acc = 0, n_recheck = 0;
 
     int top = 0;
     {
@@ -716,17 +730,43 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
             const float dx = nx - xi, dy = ny - yi;
             const float d2 = __builtin_fmaf(dy, dy, dx * dx);
             const float r2 = d2 + eps2;
+            const bool leaf = __float_as_uint(nw) & 0x80000000u;  // wave-uniform
+            // primary threshold: the pair cutoff for a body, the opening distance for a cell
+            const float th = ri - nw;
+            const float t2 = leaf ? th * th : nw;
+            const float g = d2 - t2;
+            bool pass = leaf ? g >= 0.f : g > 0.f;  // body: not colliding; cell: accepted
+            bool far = true;                         // cell only: outside 2 r_i + th
+            bool amb = __builtin_fabsf(g) <= t2 * TR_BAND;
+            if (!leaf) {
+                const float g2 = d2 - thn2;
+                far = g2 >= 0.f;
+                amb = amb || (pass && __builtin_fabsf(g2) <= thn2_band);
+            }
+            if (__ballot(act && amb) != 0ull) {
+                // Rare: decide as the reference does, in FP64 on the FP64 positions
+                // (Vector::getDistance, vector.cpp:31-35).
+                const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
+                const double *nc = a.node_com + 4 * (size_t)uj;
+                const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
+                const double dist = sqrt(ex * ex + ey * ey);
+                const double wq = nc[3];
+                if (leaf) {
+                    pass = !(rd + (-wq) + a.collision_th > dist);
+                } else {
+                    pass = wq / dist < a.theta;
+                    far = !(rd * 2 + a.collision_th > dist);
+                }
+                if (STATS)
+                    n_recheck += 1;
+            }
             bool ok;
-            if (__float_as_uint(nw) & 0x80000000u) {
-                // a body: skipped when r_i + r_j + th > dist, or when it is the body itself
-                // (barnesHut.cpp:59); the body itself has d2 == 0
-                const float th = ri - nw;
-                ok = act && d2 >= th * th && d2 > 0.f;
+            if (leaf) {
+                // the body itself has d2 == 0 (barnesHut.cpp:59 skips it by pointer)
+                ok = act && pass && d2 > 0.f;
             } else {
-                // a cell: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened
-                const bool accept = d2 > nw;
-                ok = act && accept && d2 >= thn2;
-                const uint64_t om = __ballot(act && !accept);
+                ok = act && pass && far;
+                const uint64_t om = __ballot(act && !pass);
                 if (om != 0ull) {
                     const int cf = __builtin_amdgcn_readlane((int)ch.x, j);
                     const int nc = __builtin_amdgcn_readlane((int)ch.y, j);
@@ -761,6 +801,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     if (STATS && lane == 0) {
         atomicAdd(&a.counters[0], n_eval);
         atomicAdd(&a.counters[1], n_acc);
+        atomicAdd(&a.counters[4], n_recheck);
     }
     if (!valid)
         return;
@@ -775,7 +816,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     if (a.ia.do_integrate) {
         const double2 aa = dynamic ? make_double2(ax, ay) : a.acc[body];
         double2 v = a.vel[body];
-        double2 p = a.pos[body];
+        double2 p = pd;
         v.x += aa.x * a.ia.dt;
         v.y += aa.y * a.ia.dt;
         p.x += v.x * a.ia.dt;
@@ -803,6 +844,10 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     f.posm_s = b.posm_s;
     f.node_rec = b.node_rec;
     f.node_child = b.node_child;
+    f.node_com = b.node_com;
+    f.radius = a.radius;
+    f.theta = a.theta;
+    f.collision_th = a.collision_th;
     f.idx = b.idx[b.sorted];
     f.tlist = nullptr;
     f.tcount = nullptr;

@@ -9,12 +9,9 @@
 
 #include "nbody.h"
 
-namespace nb {
+#include "nb_error.h"
 
-// ---- error plumbing (the reference prints and exits, src/gpu/BH/err.h:21-46; here every
-// failure becomes a status code plus a thread-local message) ----
-void set_error(const std::string &msg);
-int fail(int status, const std::string &msg);
+namespace nb {
 
 #define NB_HIP(call)                                                                            \
     do {                                                                                        \
@@ -58,11 +55,12 @@ struct IntegrateArgs {
 
 // ---- direct sum (nb_direct.hip) ----
 // posm: {x, y, m, radius + collision_th} per body in internal units (float4), n records.
-// Integrates targets [t0, t0+nt): reads posm_cur, writes pos/vel/acc (double2) and the
-// targets' records of posm_next.  part: scratch of jsplit*nt double2 when jsplit > 1.
+// Integrates targets [t0, t0+nt): reads posm_cur and pos_cur, writes vel/acc and the targets'
+// entries of pos_next and posm_next (nothing the step reads is written by it).  part: scratch of jsplit*nt double2 when jsplit > 1.
 int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const float *rad, int n, int t0, int nt,
-                const ForceConsts &fc, const IntegrateArgs &ia, const uint8_t *dyn, double2 *pos, double2 *vel,
-                double2 *acc, double2 *part, int jsplit);
+                const ForceConsts &fc, const IntegrateArgs &ia, const uint8_t *dyn, const double2 *pos_cur,
+                double2 *pos_next, const double *radius, double collision_th, double2 *vel, double2 *acc,
+                double2 *part, int jsplit);
 int direct_choose_jsplit(int n, int nt);
 
 // pos/mass/radius (double) -> posm records + scaled radius, bodies [i0, i1)

@@ -21,13 +21,19 @@ namespace nb {
 
 constexpr int DS_BLOCK = 256;
 constexpr int DS_TILE = 1024;  // records per LDS tile (16 KiB), two buffers
+// A float cutoff comparison closer than this fraction is repeated in FP64: the float distance
+// carries the coordinates' rounding (2^-24 of the domain each), a few 1e-6 of the cutoff.
+constexpr float DS_BAND = 4.0e-5f;
 
 struct DirectLaunch {
     const float4 *posm_cur;
     float4 *posm_next;
     const float *rad;
     const uint8_t *dyn;
-    double2 *pos;
+    const double2 *pos_cur;  // FP64 positions the step starts from (never written by the step)
+    double2 *pos_next;       // FP64 positions after the step
+    const double *radius;
+    double collision_th;
     double2 *vel;
     double2 *acc;
     double2 *part;
@@ -51,13 +57,13 @@ __device__ __forceinline__ void integrate_one(const DirectLaunch &a, int i, doub
     a.acc[i] = make_double2(ax, ay);
     if (a.ia.do_integrate) {
         double2 v = a.vel[i];
-        double2 p = a.pos[i];
+        double2 p = a.pos_cur[i];
         v.x += ax * a.ia.dt;
         v.y += ay * a.ia.dt;
         p.x += v.x * a.ia.dt;
         p.y += v.y * a.ia.dt;
         a.vel[i] = v;
-        a.pos[i] = p;
+        a.pos_next[i] = p;
         rec.x = (float)(p.x * a.ia.inv_len_unit);
         rec.y = (float)(p.y * a.ia.inv_len_unit);
         a.posm_next[i] = rec;
@@ -88,6 +94,12 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
 #pragma unroll
     for (int k = 0; k < TPT; ++k)
         sx[k] = sy[k] = 0.0;
+    int ti[TPT];
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+        int i = tbase + tid + k * DS_BLOCK;
+        ti[k] = i < tend ? i : tend - 1;
+    }
 
     const int jbeg = blockIdx.y * a.tiles_per_split * DS_TILE;
     int jend = jbeg + a.tiles_per_split * DS_TILE;
@@ -144,7 +156,21 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
                     s = (b.z * rinv) * (rinv * rinv);
                 }
                 // DirectSum::isCollide skips r_i + r_j + th >= dist (directSum.cpp:69-72)
-                s = r2 > th2 ? s : 0.f;
+                bool pass = r2 > th2;
+                const bool amb = __builtin_fabsf(r2 - th2) <= th2 * DS_BAND;
+                if (__ballot(amb) != 0ull) {
+                    // Rare: the float distance is within its own rounding of the cutoff; decide
+                    // in FP64 on the FP64 positions as the reference does (vector.cpp:31-35).
+                    const int j = jbeg + t * DS_TILE + jj;
+                    if (amb && j < jend) {
+                        const double2 pj = a.pos_cur[j];
+                        const double2 pi = a.pos_cur[ti[k]];
+                        const double ex = pj.x - pi.x, ey = pj.y - pi.y;
+                        const double dist = sqrt(ex * ex + ey * ey);
+                        pass = !(a.radius[ti[k]] + a.radius[j] + a.collision_th >= dist) && j != ti[k];
+                    }
+                }
+                s = pass ? s : 0.f;
                 fx[k] = __builtin_fmaf(dx, s, fx[k]);
                 fy[k] = __builtin_fmaf(dy, s, fy[k]);
             }
@@ -233,8 +259,9 @@ int direct_choose_jsplit(int n, int nt)
 }
 
 int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const float *rad, int n, int t0, int nt,
-                const ForceConsts &fc, const IntegrateArgs &ia, const uint8_t *dyn, double2 *pos, double2 *vel,
-                double2 *acc, double2 *part, int jsplit)
+                const ForceConsts &fc, const IntegrateArgs &ia, const uint8_t *dyn, const double2 *pos_cur,
+                double2 *pos_next, const double *radius, double collision_th, double2 *vel, double2 *acc,
+                double2 *part, int jsplit)
 {
     if (nt <= 0)
         return NB_OK;
@@ -245,7 +272,10 @@ int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const 
     a.posm_next = posm_next;
     a.rad = rad;
     a.dyn = dyn;
-    a.pos = pos;
+    a.pos_cur = pos_cur;
+    a.pos_next = pos_next;
+    a.radius = radius;
+    a.collision_th = collision_th;
     a.vel = vel;
     a.acc = acc;
     a.part = part;

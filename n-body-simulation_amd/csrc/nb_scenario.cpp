@@ -6,11 +6,15 @@
 // srand(seed)/rand(), the angle drawn before the radius, bodies in index order,
 // the same floating-point expressions.  The reference seeds with time(NULL); here
 // the seed is an argument.
+//
+// Built with g++ like the reference's CPU program: the last bit of cos/sin depends on
+// whether the compiler pairs them into one sincos call, and the fixtures were made with g++.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 
-#include "nb_common.h"
+#include "nb_error.h"
+#include "nbody.h"
 
 namespace {
 

@@ -1,0 +1,229 @@
+"""Parity of the HIP direct-sum path (through the C ABI) with the reference.
+
+Bar: per-body acceleration within 1e-5 relative of the reference direct sum
+(|a - a_ref| / |a_ref|, FP32 kernel vs FP64 reference), every body, no exclusions: a float
+cutoff comparison that is too close to call is re-decided in FP64 by the kernel, so the
+set of skipped pairs equals the reference's.  Trajectories after 100 steps: positions
+within 1e-6 of the system's extent for the orbiting scenarios (state is integrated in FP64;
+only the FP32 force rounding accumulates).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import bodies_from_golden, golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+ACC_TOL = 1e-5
+TRAJ_TOL = 1e-6
+
+
+def gpu_accel(nb, b, alg, params=None):
+    with nb.NBodySim(len(b), alg, params) as sim:
+        sim.set_bodies(b)
+        return sim.compute_accel()
+
+
+def test_solar_system_known_answers(nb):
+    """The values the reference prints for its 5-body scenario, 1 and 100 steps."""
+    with nb.NBody(5, nb.DIRECT, 2) as sim:
+        sim.update()
+        s1 = sim.read_bodies()
+        assert s1["pos"][0, 0] == pytest.approx(149596294976.13806, rel=1e-9)
+        assert s1["pos"][0, 1] == 745000000.0
+        assert s1["vel"][0, 0] == pytest.approx(-148.20095447794509, rel=1e-6)
+        assert s1["acc"][0, 0] == pytest.approx(-0.005928038179117804, rel=1e-6)
+        assert s1["acc"][2, 0] == pytest.approx(-0.039573234139035962, rel=1e-6)
+        assert np.all(s1["pos"][4] == 0) and np.all(s1["vel"][4] == 0) and np.all(s1["acc"][4] == 0)
+        sim.update(99)
+        s100 = sim.read_bodies()
+    expect = np.array(
+        [
+            [131256301024.06088, 71458106727.478882],
+            [219882076684.75839, 59548709506.070251],
+            [-28808843896.008045, 49776650490.252937],
+            [74258735237.716614, 78218074445.492767],
+        ]
+    )
+    assert np.max(np.linalg.norm(s100["pos"][:4] - expect, axis=1)) / 2.3e11 < TRAJ_TOL
+
+
+@pytest.mark.parametrize("name", ["solar_n5", "spiral_n256", "random_n256", "collision_n256",
+                                  "spiral_n4096", "random_n4096", "collision_n4096"])
+def test_accel_matches_reference_golden(nb, name):
+    g = golden(name)
+    b = bodies_from_golden(g)
+    acc = gpu_accel(nb, b, nb.DIRECT)
+    err = rel_err(acc, g["acc_direct"])
+    assert err.max() <= ACC_TOL, (name, err.max())
+    # static bodies: exactly zero, as DirectSum::calculateAcceleration leaves them
+    assert np.all(acc[b["is_dynamic"] == 0] == 0)
+
+
+@pytest.mark.parametrize("name", ["solar_n5", "spiral_n256", "collision_n256", "spiral_n4096", "collision_n4096"])
+def test_100_step_trajectory_matches_reference_golden(nb, name):
+    g = golden(name)
+    b = bodies_from_golden(g)
+    with nb.NBodySim(len(b), nb.DIRECT) as sim:
+        sim.set_bodies(b)
+        sim.update(100)
+        out = sim.read_bodies()
+    extent = np.linalg.norm(g["pos_direct_100"], axis=1).max()
+    dpos = np.linalg.norm(out["pos"] - g["pos_direct_100"], axis=1).max() / extent
+    assert dpos <= TRAJ_TOL * (10 if "collision" in name else 1), (name, dpos)
+    vscale = np.linalg.norm(g["vel_direct_100"], axis=1).max()
+    dvel = np.linalg.norm(out["vel"] - g["vel_direct_100"], axis=1).max() / vscale
+    # tight orbits (63 steps per revolution at the inner edge) turn a position lag into a
+    # velocity-direction error: v dx / r, an order above the position error
+    assert dvel <= 1e-4, (name, dvel)
+
+
+@pytest.mark.parametrize("name", ["random_n256", "random_n4096"])
+def test_random_scenario_trajectory(nb, name):
+    """Bodies start at rest and fall through the sun's cutoff sphere, where the force switches
+    off discontinuously: trajectories are chaotic there.  Most bodies must still follow the
+    reference closely; the few that crossed a cutoff boundary a step apart may not."""
+    g = golden(name)
+    b = bodies_from_golden(g)
+    with nb.NBodySim(len(b), nb.DIRECT) as sim:
+        sim.set_bodies(b)
+        sim.update(100)
+        out = sim.read_bodies()
+    extent = np.linalg.norm(g["pos_direct_100"], axis=1).max()
+    dpos = np.linalg.norm(out["pos"] - g["pos_direct_100"], axis=1) / extent
+    assert np.median(dpos) <= TRAJ_TOL
+    assert np.mean(dpos <= 1e-4) >= 0.97
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 511, 513, 1023, 1025, 2049, 3000])
+def test_ragged_sizes(nb, oracle, n):
+    b = oracle.scenario(1, n, 99)
+    if n > 1:
+        b["vel"][: n - 1] = np.random.default_rng(n).normal(0, 1e4, (n - 1, 2))
+    acc = gpu_accel(nb, b, nb.DIRECT)
+    ref = oracle.direct_accel(b)
+    assert rel_err(acc, ref).max() <= ACC_TOL
+    with nb.NBodySim(n, nb.DIRECT) as sim:
+        sim.set_bodies(b)
+        sim.update(3)
+        out = sim.read_bodies()
+    ref3 = oracle.direct_step(b, 3)
+    assert np.linalg.norm(out["pos"] - ref3["pos"], axis=1).max() <= 1e-7 * 5e11
+
+
+def test_large_n_sampled_targets(nb, oracle):
+    """config: spiral galaxy N = 65,536, FP32 direct sum; 2048 sampled targets against the oracle."""
+    n = 65536
+    b = nb.init_scenario(nb.SPIRAL, n)
+    acc = gpu_accel(nb, b, nb.DIRECT)
+    targets = np.sort(np.random.default_rng(7).choice(n, 2048, replace=False)).astype(np.int32)
+    ref = oracle.direct_accel_list(b, targets)
+    err = rel_err(acc[targets], ref)
+    assert err.max() <= ACC_TOL, err.max()
+
+
+def test_pairs_at_the_cutoff_follow_the_reference(nb, oracle):
+    """Pairs placed within float rounding of the cutoff distance r_i + r_j + 1e10 on both
+    sides: the skipped set must equal the FP64 reference's (directSum.cpp:69-72, note >=)."""
+    rng = np.random.default_rng(5)
+    n = 512
+    b = oracle.scenario(1, n, 4)
+    th = 2 * 12756 + 1.0e10
+    for k in range(0, n - 2, 2):
+        ang = rng.uniform(0, 2 * np.pi)
+        d = th * (1 + rng.choice([-1, 1]) * 10.0 ** rng.uniform(-12, -6))
+        b["pos"][k + 1] = b["pos"][k] + d * np.array([np.cos(ang), np.sin(ang)])
+    acc = gpu_accel(nb, b, nb.DIRECT)
+    ref = oracle.direct_accel(b)
+    assert rel_err(acc, ref).max() <= ACC_TOL
+
+
+def test_softened_force_without_cutoff(nb, oracle):
+    """collision_th = 0 with a large epsilon exercises the exact r^3 + eps^2 denominator."""
+    n = 700
+    b = oracle.scenario(0, n, 11)
+    b["radius"] = 0.0
+    kw = dict(collision_th=0.0, eps=3.0e9)
+    acc = gpu_accel(nb, b, nb.DIRECT, nb.default_params(**kw))
+    ref = oracle.direct_accel(b, oracle.params(**kw))
+    assert rel_err(acc, ref).max() <= ACC_TOL
+
+
+def test_parameters_are_honoured(nb, oracle):
+    n = 300
+    b = oracle.scenario(0, n, 21)
+    kw = dict(gravity=1.0e-10, dt=1000.0, collision_th=3.0e10)
+    with nb.NBodySim(n, nb.DIRECT, nb.default_params(**kw)) as sim:
+        sim.set_bodies(b)
+        sim.update(5)
+        out = sim.read_bodies()
+    ref = oracle.direct_step(b, 5, oracle.params(**kw))
+    assert rel_err(out["acc"], ref["acc"]).max() <= ACC_TOL
+    assert np.linalg.norm(out["pos"] - ref["pos"], axis=1).max() <= 1e-9 * 5e11
+
+
+def test_static_body_with_velocity_moves_unaccelerated(nb, oracle):
+    b = oracle.scenario(0, 64, 2)
+    b["vel"][63] = (1.0e3, -2.0e3)  # the static sun drifts: calculateVelocity/Position treat all bodies
+    with nb.NBodySim(64, nb.DIRECT) as sim:
+        sim.set_bodies(b)
+        sim.update(4)
+        out = sim.read_bodies()
+    ref = oracle.direct_step(b, 4)
+    assert np.allclose(out["pos"][63], ref["pos"][63], rtol=0, atol=1e-3)
+    assert np.all(out["vel"][63] == b["vel"][63])
+
+
+def _hip():
+    return C.CDLL("libamdhip64.so")
+
+
+def test_two_rank_partition_equals_single_rank(nb, oracle):
+    """Two handles own half the targets each; positions are exchanged through the exchange
+    buffers as an all-gather would.  The result must equal the unpartitioned run bit for bit."""
+    n = 3001
+    b = oracle.scenario(0, n, 8)
+    hip = _hip()
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    with nb.NBodySim(n, nb.DIRECT) as one, nb.NBodySim(n, nb.DIRECT) as r0, nb.NBodySim(n, nb.DIRECT) as r1:
+        for s in (one, r0, r1):
+            s.set_bodies(b)
+        r0.set_partition(0, 2)
+        r1.set_partition(1, 2)
+        for _ in range(5):
+            one.update()
+            for s in (r0, r1):
+                s.step_local()
+            for s in (r0, r1):
+                s.sync()
+            p0, chunk, rb = r0.exchange_buffer()
+            p1, _, _ = r1.exchange_buffer()
+            assert chunk == (n + 1) // 2 and rb == 16
+            # all-gather: slice k of every rank <- rank k's slice
+            assert hip.hipMemcpy(p1, p0, chunk * rb, 3) == 0
+            n1 = n - chunk
+            assert hip.hipMemcpy(p0 + chunk * rb, p1 + chunk * rb, n1 * rb, 3) == 0
+            for s in (r0, r1):
+                s.step_finish()
+        ref = one.read_bodies()
+        a = r0.read_bodies()
+        c = r1.read_bodies()
+    assert np.array_equal(a["pos"], ref["pos"]) and np.array_equal(c["pos"], ref["pos"])
+    assert np.array_equal(a["vel"][:chunk], ref["vel"][:chunk])
+    assert np.array_equal(c["vel"][chunk:], ref["vel"][chunk:])
+
+
+def test_call_order_errors(nb):
+    with nb.NBodySim(16, nb.DIRECT) as sim:
+        with pytest.raises(nb.NBodyError, match="no bodies"):
+            sim.update()
+        sim.setup(nb.RANDOM, 1)
+        with pytest.raises(nb.NBodyError, match="nb_step_local was not called"):
+            sim.step_finish()
+        with pytest.raises(nb.NBodyError):
+            sim.set_bodies(nb.make_bodies(15))
+        sim.set_partition(0, 2)
+        with pytest.raises(nb.NBodyError, match="partitioned"):
+            sim.update()
