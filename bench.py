@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Benchmark of the N-body hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Headline (BASELINE.json's metric, the configuration the reference publishes a number for):
+Barnes-Hut ms/step, galaxy collision, N = 5,000,000, theta = 0.5 -- the reference's README
+quotes 1509 ms/iteration for it on an unnamed NVIDIA GPU.  A "step" is one full update of all
+bodies: bounding box, keys, sort, tree build, centre of mass, traversal + integration.  Bodies
+are resident in HBM before the timed region.  The second half of the metric, direct-sum
+G interactions/s, is measured in the same run (N = 65,536 and N = 1,000,000) and reported in
+"direct_sum".
+
+With N > 1 the driver starts one rank per GPU (torch.distributed.run); every rank holds all
+bodies, integrates its slice and all-gathers positions over RCCL each step (strong scaling:
+the total work is fixed).
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib.util
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "n-body-simulation_amd")
+
+PUBLISHED_MS = 1509.0           # reference README.md:18, GPU Barnes-Hut N = 5M per iteration
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, spec
+VALU_PEAK_TFLOPS = 157.3        # MI355X FP32 vector peak, spec (256 CU x 128 lanes x 2 x 2.4 GHz)
+FLOP_PER_INTERACTION = 20       # GPU Gems 3 ch. 31 convention
+BH_FORCE_BYTES_PER_BODY = 128   # traversal + integrate: own state 32 r + 32 w, each of ~2N 32-B nodes once
+
+
+def load_package():
+    path = os.path.join(PKG, "__init__.py")
+    spec = importlib.util.spec_from_file_location("nbody_amd", path, submodule_search_locations=[PKG])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["nbody_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=True):
+    """Returns (seconds for `steps` steps, max over ranks; mean per-stage ms of this rank)."""
+    from nbody_amd.distributed import DistributedSim, GpuEngine
+
+    sim = nb.NBodySim(len(bodies), alg)
+    sim.set_bodies(bodies)
+    eng = GpuEngine(sim, device)
+    if world > 1:
+        stepper = DistributedSim(eng)
+        step = lambda: stepper.update(1)  # noqa: E731
+    else:
+        step = lambda: sim.update(1)  # noqa: E731
+    for _ in range(warmup):
+        step()
+    sim.set_stage_timing(stage_timing, counters=False)
+    stages = {}
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        if stage_timing:
+            for k, v in sim.stage_ms().items():
+                stages[k] = stages.get(k, 0.0) + v / steps
+    barrier_sync(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    counters = None
+    if alg == nb.BARNES_HUT and rank == 0:
+        sim.set_stage_timing(False, counters=True)
+        step()
+        torch.cuda.synchronize()
+        c = sim.debug(nb.DBG_COUNTERS, np.uint64, 8)
+        counters = {"node_evaluations": int(c[0]), "accepted_interactions": int(c[1]), "nodes": int(c[2]),
+                    "levels": int(c[3]), "fp64_redecisions": int(c[4])}
+    elif alg == nb.BARNES_HUT and world > 1:
+        step()  # keep the ranks' collectives matched with rank 0's extra step
+    sim.close()
+    return dt, stages, counters
+
+
+def cpu_baseline(nb, bh_n):
+    """The reference's CPU Barnes-Hut (its own classes when the prebuilt library is present,
+    else the plain-C port) on a bounded sample: one step of the same scenario at a smaller N."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle, Reference
+
+    sample_n = 400000
+    b = nb.init_scenario(nb.COLLISION, sample_n, 12345)
+    if Reference.available():
+        ref = Reference()
+        kind = "reference"
+        t0 = time.perf_counter()
+        ref.step(1, b, 1)
+        dt = time.perf_counter() - t0
+        td = None
+        bd = nb.init_scenario(nb.SPIRAL, 16384, 12345)
+        t0 = time.perf_counter()
+        ref.step(0, bd, 1)
+        td = time.perf_counter() - t0
+    else:
+        orc = Oracle()
+        kind = "port"
+        t0 = time.perf_counter()
+        orc.bh_step(b, 1)
+        dt = time.perf_counter() - t0
+        bd = nb.init_scenario(nb.SPIRAL, 16384, 12345)
+        t0 = time.perf_counter()
+        orc.direct_step(bd, 1)
+        td = time.perf_counter() - t0
+    scale = (bh_n * math.log2(bh_n)) / (sample_n * math.log2(sample_n))
+    return {
+        "value": dt * 1e3,
+        "unit": "ms/step at N=%d" % sample_n,
+        "cores": 1,
+        "kind": kind,
+        "sample": "1 step of the reference CPU BarnesHut::update, galaxy collision N=%d (same generator and "
+                  "seed as the workload, 8%% of its bodies), single thread (the reference has no threading)" % sample_n,
+        "scaled_to_workload_ms": dt * 1e3 * scale,
+        "scaling_rule": "N log2 N",
+        "direct_sum_ginteractions_per_s": 16384.0 * 16384.0 / td / 1e9,
+        "direct_sum_sample": "1 step of the reference CPU DirectSum::update, spiral N=16384",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bh-n", type=int, default=5000000)
+    ap.add_argument("--direct-n", type=int, default=1000000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-direct", action="store_true", help="skip the direct-sum half of the metric")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    nb = load_package()
+
+    # ---- headline: Barnes-Hut, galaxy collision N = 5M ----
+    bodies = nb.init_scenario(nb.COLLISION, args.bh_n, 12345)
+    dt, stages, counters = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device)
+    ms_per_step = dt * 1e3 / args.steps
+    del bodies
+
+    # ---- second half of the metric: direct-sum G interactions/s ----
+    direct = None
+    if not args.no_direct:
+        direct = {}
+        for n, steps, warm in ((65536, max(args.steps, 10), 3), (args.direct_n, 3, 1)):
+            b = nb.init_scenario(nb.SPIRAL, n, 12345)
+            ddt, dstages, _ = timed_run(nb, nb.DIRECT, b, steps, warm, rank, world, device)
+            gi = float(n) * n * steps / ddt / 1e9
+            kern_ms = dstages.get("force", 0.0)
+            entry = {"n": n, "steps": steps, "ms_per_step": ddt * 1e3 / steps, "ginteractions_per_s": gi,
+                     "scenario": "spiral"}
+            if world == 1 and kern_ms > 0:
+                tf = float(n) * n * FLOP_PER_INTERACTION / (kern_ms * 1e-3) / 1e12
+                entry["roofline"] = {"bound": "valu_fp32", "kernel": "k_direct", "achieved": tf,
+                                     "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
+                                     "kernel_ms": kern_ms, "flop_per_interaction": FLOP_PER_INTERACTION,
+                                     "traffic": None}
+            direct["n%d" % n] = entry
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel of the headline step (the traversal) ----
+    force_ms = stages.get("force", 0.0)
+    per_rank_bodies = args.bh_n / world
+    alg_bytes = BH_FORCE_BYTES_PER_BODY * per_rank_bodies
+    achieved = alg_bytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and world == 1:
+        try:
+            traffic = json.load(open(tpath)).get("k_bh_force", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_bh_force", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": force_ms,
+                "algorithmic_bytes_per_launch": alg_bytes}
+    if counters and force_ms > 0:
+        roofline["body_node_interactions_per_s"] = counters["accepted_interactions"] / (force_ms * 1e-3)
+        roofline["node_evaluations_per_s"] = counters["node_evaluations"] / (force_ms * 1e-3)
+
+    out = {
+        "metric": "Barnes-Hut ms/step at N=5M",
+        "value": ms_per_step,
+        "unit": "ms/step",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": False,
+        "scaling": "strong",
+        "vs_baseline": ms_per_step / PUBLISHED_MS,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "galaxy collision N=%d Barnes-Hut theta=0.5, 2-D (BASELINE.json configs[3]); forces FP32, "
+                        "state and integration FP64" % args.bh_n,
+            "scenario_seed": 12345,
+            "parallelism": "targets split over %d GPU(s), tree rebuilt on every GPU, all-gather of positions" % world,
+        },
+        "speedup_vs_published": PUBLISHED_MS / ms_per_step,
+        "stage_ms": stages,
+        "tree": counters,
+        "roofline": roofline,
+        "direct_sum": direct,
+    }
+    if world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(nb, args.bh_n)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

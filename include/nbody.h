@@ -130,8 +130,10 @@ int nb_set_stream(nb_sim *sim, void *hip_stream);
 
 /* ---- multi-GPU: one process per GPU, every process holds all n bodies ---- */
 
-/* This process integrates only the bodies whose position in the exchange order
- * lies in [rank*chunk, min(n,(rank+1)*chunk)), chunk = nb_exchange_chunk().
+/* Bodies are held in "exchange order": sorted once, when they are set, by a Morton code of
+ * their initial positions (NB_DBG_ORDER gives the caller index of each slot), so that an
+ * index range is a compact patch of space.  This process integrates only the bodies in slots
+ * [rank*chunk, min(n,(rank+1)*chunk)), chunk = ceil(n / world).
  * Must be called after the bodies were set and before the first step. */
 int nb_set_partition(nb_sim *sim, int rank, int world);
 
@@ -164,7 +166,9 @@ enum nb_debug_array {
 /* Copies the array into out (bytes = capacity of out); *written gets the size. */
 int nb_debug_read(nb_sim *sim, int which, void *out, size_t bytes, size_t *written);
 
-/* Milliseconds spent per stage in the last nb_step(sim, 1) when timing is on:
+/* on: bit 0 = time every stage with HIP events on the simulation's stream (nb_step then
+ * waits for the stream), bit 1 = collect the NB_DBG_COUNTERS statistics (slower traversal).
+ * nb_stage_ms: milliseconds per stage of the last step or nb_compute_accel:
  * [0] bbox [1] keys [2] sort [3] build [4] com [5] force+integrate [6] other. */
 int nb_set_stage_timing(nb_sim *sim, int on);
 int nb_stage_ms(nb_sim *sim, float *out, int count);

@@ -187,8 +187,14 @@ class NBodySim:
     def step_finish(self):
         _check(self._lib.nb_step_finish(self._h))
 
-    def set_stage_timing(self, on=True):
-        _check(self._lib.nb_set_stage_timing(self._h, 1 if on else 0))
+    def set_stage_timing(self, on=True, counters=None):
+        """on: per-stage hipEvent timing; counters (default: same as on): traversal statistics."""
+        counters = on if counters is None else counters
+        _check(self._lib.nb_set_stage_timing(self._h, (1 if on else 0) | (2 if counters else 0)))
+
+    def order(self):
+        """Caller index of the body held in each exchange-order slot."""
+        return self.debug(DBG_ORDER, np.uint32, self.n)
 
     def stage_ms(self):
         out = (C.c_float * 8)()

@@ -63,6 +63,7 @@ struct nb_sim {
     // direct sum
     double2 *part = nullptr;
     int jsplit = 1;
+    uint8_t *ds_meta = nullptr;  // per-run bounding boxes (direct_meta_bytes)
 
     // Barnes-Hut
     BhBuffers bh;
@@ -110,6 +111,38 @@ void choose_units(nb_sim *s, const nb_body *b, int n)
     s->fc.exact_denom = !((double)s->fc.eps3 <= std::ldexp(c3, -26));
 }
 
+// Exchange order = bodies sorted by a 2 x 16-bit Morton code of their initial positions.
+// Index ranges of it are compact patches of space, which keeps the 64 bodies a wave walks the
+// tree for close together when the range is cut across GPUs, and gives the direct-sum tiles
+// small bounding boxes.  Only locality matters here, not the reference's cell boundaries.
+void exchange_order(const nb_body *b, int n, std::vector<uint32_t> &order)
+{
+    order.resize(n);
+    double mnx = b[0].position.x, mxx = mnx, mny = b[0].position.y, mxy = mny;
+    for (int i = 1; i < n; ++i) {
+        mnx = std::min(mnx, b[i].position.x);
+        mxx = std::max(mxx, b[i].position.x);
+        mny = std::min(mny, b[i].position.y);
+        mxy = std::max(mxy, b[i].position.y);
+    }
+    const double sx = mxx > mnx ? 65535.0 / (mxx - mnx) : 0.0, sy = mxy > mny ? 65535.0 / (mxy - mny) : 0.0;
+    auto spread = [](uint32_t v) {
+        v = (v | (v << 8)) & 0x00FF00FFu;
+        v = (v | (v << 4)) & 0x0F0F0F0Fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    std::vector<uint64_t> kv(n);
+    for (int i = 0; i < n; ++i) {
+        const uint32_t qx = (uint32_t)((b[i].position.x - mnx) * sx), qy = (uint32_t)((b[i].position.y - mny) * sy);
+        kv[i] = ((uint64_t)(spread(qx) | (spread(qy) << 1)) << 32) | (uint32_t)i;
+    }
+    std::sort(kv.begin(), kv.end());
+    for (int i = 0; i < n; ++i)
+        order[i] = (uint32_t)(kv[i] & 0xffffffffu);
+}
+
 IntegrateArgs integrate_args(const nb_sim *s, int do_integrate)
 {
     IntegrateArgs ia;
@@ -155,7 +188,7 @@ int step_local(nb_sim *s, int do_integrate)
         mark(s, 0);
         NB_TRY(direct_step(s->stream, s->posm[s->cur], s->posm[s->cur ^ 1], s->rad_s, s->n, s->t0, s->t1 - s->t0, s->fc,
                            integrate_args(s, do_integrate), s->dyn, s->pos, s->pos2, s->radius, s->p.collision_th,
-                           s->vel, s->acc, s->part, s->jsplit));
+                           s->vel, s->acc, s->part, s->jsplit, s->ds_meta));
         mark(s, 1);
         return NB_OK;
     }
@@ -222,6 +255,7 @@ void release(nb_sim *s)
     (void)hipFree(s->posm[1]);
     (void)hipFree(s->rad_s);
     (void)hipFree(s->part);
+    (void)hipFree(s->ds_meta);
     bh_free(s->bh);
     for (auto &e : s->ev)
         if (e)
@@ -288,6 +322,7 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
         chk(dev_alloc(s->rad_s, s->cap));
         s->jsplit = direct_choose_jsplit(n, n);
         chk(dev_alloc(s->part, (size_t)s->jsplit * n));
+        chk(dev_alloc(s->ds_meta, direct_meta_bytes(n)));
     } else {
         chk(bh_alloc(s->bh, n));
     }
@@ -335,8 +370,7 @@ int nb_set_bodies(nb_sim *s, const nb_body *b, int n)
         if (!std::isfinite(b[i].position.x) || !std::isfinite(b[i].position.y) || !std::isfinite(b[i].mass))
             return fail(NB_ERR_ARG, "nb_set_bodies: body " + std::to_string(i) + " is not finite");
     choose_units(s, b, n);
-    s->order.resize(n);
-    std::iota(s->order.begin(), s->order.end(), 0u);
+    exchange_order(b, n, s->order);
     std::vector<double2> pos(n), vel(n), acc(n);
     std::vector<double> mass(n), radius(n);
     std::vector<uint8_t> dyn(n);
@@ -401,7 +435,7 @@ int nb_step_finish(nb_sim *s)
         return fail(NB_ERR_STATE, "nb_step_finish: nb_step_local was not called");
     NB_TRY(step_finish(s));
     s->mid_step = false;
-    return NB_OK;
+    return collect_timing(s);
 }
 
 int nb_step(nb_sim *s, int nsteps)
@@ -483,8 +517,6 @@ int nb_set_partition(nb_sim *s, int rank, int world)
         return fail(NB_ERR_ARG, "nb_set_partition: need 0 <= rank < world <= 64");
     if (!s->have_bodies)
         return fail(NB_ERR_STATE, "nb_set_partition: set the bodies first");
-    if (s->alg == NB_ALG_BARNES_HUT && world > 1)
-        return fail(NB_ERR_STATE, "nb_set_partition: Barnes-Hut runs on one GPU in this version");
     s->rank = rank;
     s->world = world;
     s->chunk = ((size_t)s->n + world - 1) / world;
@@ -508,8 +540,8 @@ int nb_set_stage_timing(nb_sim *s, int on)
 {
     if (!s)
         return fail(NB_ERR_ARG, "nb_set_stage_timing: sim is NULL");
-    s->timing = on ? 1 : 0;
-    s->collect_stats = on ? 1 : 0;
+    s->timing = (on & 1) ? 1 : 0;
+    s->collect_stats = (on & 2) ? 1 : 0;
     return NB_OK;
 }
 

@@ -38,6 +38,7 @@ struct BhBuffers {
     uint2 *node_child = nullptr;  // first child, child count
     uint32_t *tlist = nullptr;    // sorted positions of this rank's targets (multi-GPU), else unused
     uint32_t *tcount = nullptr;   // 1 entry: number of targets in tlist
+    uint32_t *tblock = nullptr;   // per-block target counts (scratch of the compaction)
     unsigned long long *counters = nullptr;  // 8 statistics words
 };
 

@@ -826,6 +826,55 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     }
 }
 
+
+// ---- targets of this rank (multi-GPU): sorted positions k whose body lies in [t0, t1) ----
+
+constexpr int TL_ITEMS = 8;
+constexpr int TL_TILE = 256 * TL_ITEMS;
+
+__global__ __launch_bounds__(256) void k_tl_count(const uint32_t *idx, int n, uint32_t t0, uint32_t t1, uint32_t *bcount)
+{
+    const int base = blockIdx.x * TL_TILE + threadIdx.x * TL_ITEMS;
+    int c = 0;
+#pragma unroll
+    for (int it = 0; it < TL_ITEMS; ++it) {
+        const int k = base + it;
+        if (k < n) {
+            const uint32_t o = idx[k];
+            c += (o >= t0 && o < t1) ? 1 : 0;
+        }
+    }
+    const int tot = block_sum_256(c);
+    if (threadIdx.x == 0)
+        bcount[blockIdx.x] = (uint32_t)tot;
+}
+
+__global__ __launch_bounds__(256) void k_tl_emit(const uint32_t *idx, int n, uint32_t t0, uint32_t t1,
+                                                 const uint32_t *bcount_excl, uint32_t *tlist, uint32_t *tcount)
+{
+    const int base = blockIdx.x * TL_TILE + threadIdx.x * TL_ITEMS;
+    bool own[TL_ITEMS];
+    int c = 0;
+#pragma unroll
+    for (int it = 0; it < TL_ITEMS; ++it) {
+        const int k = base + it;
+        own[it] = false;
+        if (k < n) {
+            const uint32_t o = idx[k];
+            own[it] = o >= t0 && o < t1;
+        }
+        c += own[it] ? 1 : 0;
+    }
+    int tot;
+    int pos = (int)bcount_excl[blockIdx.x] + block_excl_scan_256(c, tot);
+#pragma unroll
+    for (int it = 0; it < TL_ITEMS; ++it)
+        if (own[it])
+            tlist[pos++] = (uint32_t)(base + it);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255)
+        *tcount = (uint32_t)pos;
+}
+
 __global__ void k_bh_finish_counters(const uint32_t *level_start, unsigned long long *counters)
 {
     if (threadIdx.x == 0) {
@@ -851,6 +900,19 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     f.idx = b.idx[b.sorted];
     f.tlist = nullptr;
     f.tcount = nullptr;
+    int ntarget = a.n;
+    if (a.t0 != 0 || a.t1 != a.n) {
+        // this rank integrates only bodies [t0, t1): walk them in Morton order
+        const int nblk = (a.n + TL_TILE - 1) / TL_TILE;
+        hipLaunchKernelGGL(k_tl_count, dim3(nblk), dim3(256), 0, s, b.idx[b.sorted], a.n, (uint32_t)a.t0, (uint32_t)a.t1,
+                           b.tblock);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, b.tblock, nblk);
+        hipLaunchKernelGGL(k_tl_emit, dim3(nblk), dim3(256), 0, s, b.idx[b.sorted], a.n, (uint32_t)a.t0, (uint32_t)a.t1,
+                           b.tblock, b.tlist, b.tcount);
+        f.tlist = b.tlist;
+        f.tcount = b.tcount;
+        ntarget = a.t1 - a.t0;
+    }
     f.dyn = a.dyn;
     f.pos = a.pos_out;
     f.vel = a.vel;
@@ -859,8 +921,10 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     f.n = a.n;
     f.fc = a.fc;
     f.ia = a.ia;
-    const int waves = (a.n + 63) / 64;
+    const int waves = (ntarget + 63) / 64;
     dim3 grid((waves + 3) / 4);
+    if (ntarget <= 0)
+        return NB_OK;
     if (a.collect_stats) {
         if (a.fc.exact_denom)
             hipLaunchKernelGGL((k_bh_force<true, true>), grid, dim3(256), 0, s, f);
@@ -912,6 +976,7 @@ int bh_alloc(BhBuffers &b, int n)
     NB_TRY(dev_alloc(b.node_child, b.node_cap));
     NB_TRY(dev_alloc(b.tlist, (size_t)n));
     NB_TRY(dev_alloc(b.tcount, 4));
+    NB_TRY(dev_alloc(b.tblock, (size_t)(n + TL_TILE - 1) / TL_TILE + 1));
     NB_TRY(dev_alloc(b.counters, 8));
     return NB_OK;
 }
@@ -935,6 +1000,7 @@ void bh_free(BhBuffers &b)
     (void)hipFree(b.node_child);
     (void)hipFree(b.tlist);
     (void)hipFree(b.tcount);
+    (void)hipFree(b.tblock);
     (void)hipFree(b.counters);
     b = BhBuffers();
 }

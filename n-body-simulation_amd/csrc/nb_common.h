@@ -60,8 +60,10 @@ struct IntegrateArgs {
 int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const float *rad, int n, int t0, int nt,
                 const ForceConsts &fc, const IntegrateArgs &ia, const uint8_t *dyn, const double2 *pos_cur,
                 double2 *pos_next, const double *radius, double collision_th, double2 *vel, double2 *acc,
-                double2 *part, int jsplit);
+                double2 *part, int jsplit, void *meta);
 int direct_choose_jsplit(int n, int nt);
+// bytes of the per-run metadata scratch direct_step needs for n bodies
+size_t direct_meta_bytes(int n);
 
 // pos/mass/radius (double) -> posm records + scaled radius, bodies [i0, i1)
 int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int i0, int i1,

@@ -2,28 +2,49 @@
 //
 // Replaces DirectSumTiledKernel (src/gpu/DS/directSum_kernel.cu:61-106) with the semantics
 // of the CPU DirectSum::update (src/cpu/directSum.cpp:24-79): accelerations from the OLD
-// positions of every body, then v += a dt, x += v dt.  Positions are double-buffered
-// (records are read from posm_cur, new ones go to posm_next), so no block ever reads a
-// position another block has already advanced.
+// positions of every body, then v += a dt, x += v dt.  Everything a step reads (posm_cur,
+// pos_cur) is left untouched by it; new positions go to posm_next / pos_next.
 //
 // Data layout: one float4 record {x, y, m, radius + collision_th} per body, in internal
 // units (nb_common.h), read coalesced (16 B per lane) and staged through LDS in tiles of
-// TILE records; every lane then reads the same record per iteration (an LDS broadcast).
-// Each thread owns TPT targets, so one LDS read feeds TPT interactions.  The FP32 partial
-// sums of one tile are added to FP64 accumulators, which keeps the rounding of a
-// million-term sum at the level of a 1024-term one.
+// DS_TILE records; every lane then reads the same record per iteration (an LDS broadcast).
+// Each thread owns TPT targets, so one LDS read feeds TPT interactions.
 //
-// Per interaction (2-D): 2 sub, 3 fma, 1 add, 3 mul, 1 rsq, 1 cmp, 1 select, 2 fma.
-// Bound: FP32 vector ALU (no MFMA: there is no dense contraction here).
+// The reference's near-field cutoff (pairs closer than r_i + r_j + collision_th are skipped,
+// directSum.cpp:69-72) costs a third of the pair arithmetic, yet only concerns bodies within
+// ~1 % of the domain of each other.  Bodies are held in Morton order, so a block's targets
+// and a run of DS_SUB consecutive sources occupy small boxes; when the two boxes are farther
+// apart than the largest possible cutoff, the run is processed by a loop without the test.
+// Runs whose bodies all have one mass (the planets of every reference scenario) also skip
+// the per-pair multiply by the mass.  Runs that may hold a pair at the cutoff take the full
+// loop, in which a float comparison too close to call is repeated in FP64.
+//
+// Rounding: FP32 partial sums are folded into FP64 accumulators every DS_FLUSH pairs, so a
+// dominant term (a sun) cannot swallow the low bits of the thousand terms added after it.
+//
+// Per interaction (2-D), far run: 2 sub, 2 fma, 1 rsq, 2-3 mul, 2 fma; near run: + add, fma,
+// cmp, select and the tie test.  Bound: FP32 vector ALU (no MFMA: no dense contraction here).
 #include "nb_common.h"
 
 namespace nb {
 
 constexpr int DS_BLOCK = 256;
 constexpr int DS_TILE = 1024;  // records per LDS tile (16 KiB), two buffers
+constexpr int DS_SUB = 256;    // records per run with its own bounding box
+constexpr int DS_FLUSH = 32;   // pairs between FP32 -> FP64 folds
 // A float cutoff comparison closer than this fraction is repeated in FP64: the float distance
 // carries the coordinates' rounding (2^-24 of the domain each), a few 1e-6 of the cutoff.
 constexpr float DS_BAND = 4.0e-5f;
+// safety factor on the squared box gap that lets a run skip the cutoff test
+constexpr float DS_GAP_SLACK = 1.001f;
+
+// Bounding box of a run of DS_SUB sources, its largest cutoff radius and its common mass.
+struct SubMeta {
+    float x0, x1, y0, y1;
+    float wmax;  // max of radius + collision_th
+    float mu;    // the mass every body of the run has, or NaN when they differ
+    float pad0, pad1;
+};
 
 struct DirectLaunch {
     const float4 *posm_cur;
@@ -33,6 +54,7 @@ struct DirectLaunch {
     const double2 *pos_cur;  // FP64 positions the step starts from (never written by the step)
     double2 *pos_next;       // FP64 positions after the step
     const double *radius;
+    const SubMeta *meta;
     double collision_th;
     double2 *vel;
     double2 *acc;
@@ -45,6 +67,53 @@ struct DirectLaunch {
     ForceConsts fc;
     IntegrateArgs ia;
 };
+
+// One wave per run: min/max of x and y, max cutoff radius, common mass.
+__global__ __launch_bounds__(256) void k_sub_meta(const float4 *posm, int n, SubMeta *meta)
+{
+    const int lane = threadIdx.x & 63;
+    const int sub = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int base = sub * DS_SUB;
+    if (base >= n)
+        return;
+    float x0 = __builtin_inff(), x1 = -__builtin_inff(), y0 = __builtin_inff(), y1 = -__builtin_inff();
+    float wmax = 0.f, m0 = __builtin_inff(), m1 = -__builtin_inff();
+#pragma unroll
+    for (int q = 0; q < DS_SUB / 64; ++q) {
+        const int j = base + lane + 64 * q;
+        if (j < n) {
+            const float4 r = posm[j];
+            x0 = fminf(x0, r.x);
+            x1 = fmaxf(x1, r.x);
+            y0 = fminf(y0, r.y);
+            y1 = fmaxf(y1, r.y);
+            wmax = fmaxf(wmax, r.w);
+            m0 = fminf(m0, r.z);
+            m1 = fmaxf(m1, r.z);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o));
+        x1 = fmaxf(x1, __shfl_xor(x1, o));
+        y0 = fminf(y0, __shfl_xor(y0, o));
+        y1 = fmaxf(y1, __shfl_xor(y1, o));
+        wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+        m0 = fminf(m0, __shfl_xor(m0, o));
+        m1 = fmaxf(m1, __shfl_xor(m1, o));
+    }
+    if (lane == 0) {
+        SubMeta m;
+        m.x0 = x0;
+        m.x1 = x1;
+        m.y0 = y0;
+        m.y1 = y1;
+        m.wmax = wmax;
+        m.mu = (m0 == m1) ? m0 : __builtin_nanf("");
+        m.pad0 = m.pad1 = 0.f;
+        meta[sub] = m;
+    }
+}
 
 // v += a dt; x += v dt for one body, and its refreshed float record.
 __device__ __forceinline__ void integrate_one(const DirectLaunch &a, int i, double sx, double sy, float4 rec)
@@ -70,35 +139,171 @@ __device__ __forceinline__ void integrate_one(const DirectLaunch &a, int i, doub
     }
 }
 
+// Adds the pairs of one target with one run that the main loop left out because their float
+// cutoff comparison was too close to call: those are decided in FP64 on the FP64 positions, as
+// the reference does (Vector::getDistance, vector.cpp:31-35; isCollide, directSum.cpp:69-72).
+// Rare (a few pairs per million), so it runs as a separate loop after the hot one.
+template <bool EXACT>
+__device__ __forceinline__ double2 redo_ambiguous(const DirectLaunch &a, const float4 *rec, int jglobal, int jend,
+                                                  float xi, float yi, float ri, int ti)
+{
+    double ox = 0.0, oy = 0.0;
+    const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
+    const double2 pi = a.pos_cur[ti];
+    const double rdi = a.radius[ti];
+#pragma unroll 1
+    for (int jj = 0; jj < DS_SUB; ++jj) {
+        const float4 b = rec[jj];
+        const float dx = b.x - xi, dy = b.y - yi;
+        float r2 = __builtin_fmaf(dx, dx, eps2);
+        r2 = __builtin_fmaf(dy, dy, r2);
+        const float th = ri + b.w;
+        const float th2 = __builtin_fmaf(th, th, eps2);
+        const int j = jglobal + jj;
+        if (__builtin_fabsf(r2 - th2) <= th2 * DS_BAND && j < jend && j != ti) {
+            const double2 pj = a.pos_cur[j];
+            const double ex = pj.x - pi.x, ey = pj.y - pi.y;
+            const double dist = sqrt(ex * ex + ey * ey);
+            if (!(rdi + a.radius[j] + a.collision_th >= dist)) {
+                float s;
+                if (EXACT)
+                    s = b.z * __builtin_amdgcn_rcpf(r2 * __builtin_sqrtf(r2) + eps3);
+                else {
+                    const float rinv = __builtin_amdgcn_rsqf(r2);
+                    s = (b.z * rinv) * (rinv * rinv);
+                }
+                ox += (double)(dx * s);
+                oy += (double)(dy * s);
+            }
+        }
+    }
+    return make_double2(ox, oy);
+}
+
+// All pairs of this thread's TPT targets with one run of DS_SUB staged records.
+// CUTOFF: apply the skip test; UNIFORM: every record has mass mu.
+template <int TPT, bool EXACT, bool CUTOFF, bool UNIFORM>
+__device__ __forceinline__ void run_pairs(const DirectLaunch &a, const float4 *rec, int jglobal, int jend, float mu,
+                                          const float (&xi)[TPT], const float (&yi)[TPT], const float (&ri)[TPT],
+                                          const int (&ti)[TPT], double (&sx)[TPT], double (&sy)[TPT])
+{
+    const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
+    bool any_amb[TPT];
+#pragma unroll
+    for (int k = 0; k < TPT; ++k)
+        any_amb[k] = false;
+#pragma unroll 1
+    for (int c = 0; c < DS_SUB; c += DS_FLUSH) {
+        float fx[TPT], fy[TPT];
+#pragma unroll
+        for (int k = 0; k < TPT; ++k)
+            fx[k] = fy[k] = 0.f;
+#pragma unroll 8
+        for (int jj = 0; jj < DS_FLUSH; ++jj) {
+            const float4 b = rec[c + jj];
+#pragma unroll
+            for (int k = 0; k < TPT; ++k) {
+                const float dx = b.x - xi[k];
+                const float dy = b.y - yi[k];
+                float r2 = __builtin_fmaf(dx, dx, eps2);
+                r2 = __builtin_fmaf(dy, dy, r2);
+                float s;
+                if (EXACT) {
+                    const float r3 = r2 * __builtin_sqrtf(r2);
+                    s = __builtin_amdgcn_rcpf(r3 + eps3);
+                    if (!UNIFORM)
+                        s *= b.z;
+                } else {
+                    const float rinv = __builtin_amdgcn_rsqf(r2);
+                    s = UNIFORM ? rinv * (rinv * rinv) : (b.z * rinv) * (rinv * rinv);
+                }
+                if (CUTOFF) {
+                    const float th = ri[k] + b.w;
+                    const float th2 = __builtin_fmaf(th, th, eps2);  // d^2 > th^2 <=> d^2+eps^2 > th^2+eps^2
+                    // DirectSum::isCollide skips r_i + r_j + th >= dist (directSum.cpp:69-72).  A
+                    // comparison within the band is left out here and settled by redo_ambiguous.
+                    const float q = r2 - th2, band = th2 * DS_BAND;
+                    any_amb[k] = any_amb[k] || __builtin_fabsf(q) <= band;
+                    s = q > band ? s : 0.f;
+                }
+                fx[k] = __builtin_fmaf(dx, s, fx[k]);
+                fy[k] = __builtin_fmaf(dy, s, fy[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            sx[k] += (double)(UNIFORM ? fx[k] * mu : fx[k]);
+            sy[k] += (double)(UNIFORM ? fy[k] * mu : fy[k]);
+        }
+    }
+    if (CUTOFF) {
+#pragma unroll
+        for (int k = 0; k < TPT; ++k)
+            if (any_amb[k]) {
+                const double2 extra = redo_ambiguous<EXACT>(a, rec, jglobal, jend, xi[k], yi[k], ri[k], ti[k]);
+                sx[k] += extra.x;
+                sy[k] += extra.y;
+            }
+    }
+}
+
+__device__ __forceinline__ float uniform_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
 template <int TPT, bool EXACT>
 __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
 {
     __shared__ float4 tile[2][DS_TILE];
+    __shared__ float red[4][5];
     const int tid = threadIdx.x;
     const int tbase = a.t0 + blockIdx.x * (DS_BLOCK * TPT);
     const int tend = a.t0 + a.nt;
 
     float xi[TPT], yi[TPT], ri[TPT];
+    int ti[TPT];
     float4 self[TPT];
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
-        int i = tbase + tid + k * DS_BLOCK;
+        const int i = tbase + tid + k * DS_BLOCK;
         // threads past the end work on a copy of the last target and discard the result
-        int ic = i < tend ? i : tend - 1;
-        self[k] = a.posm_cur[ic];
+        ti[k] = i < tend ? i : tend - 1;
+        self[k] = a.posm_cur[ti[k]];
         xi[k] = self[k].x;
         yi[k] = self[k].y;
-        ri[k] = a.rad[ic];
+        ri[k] = a.rad[ti[k]];
     }
     double sx[TPT], sy[TPT];
 #pragma unroll
     for (int k = 0; k < TPT; ++k)
         sx[k] = sy[k] = 0.0;
-    int ti[TPT];
+
+    // bounding box of the block's targets and their largest radius
+    float bx0 = xi[0], bx1 = xi[0], by0 = yi[0], by1 = yi[0], rimax = ri[0];
 #pragma unroll
-    for (int k = 0; k < TPT; ++k) {
-        int i = tbase + tid + k * DS_BLOCK;
-        ti[k] = i < tend ? i : tend - 1;
+    for (int k = 1; k < TPT; ++k) {
+        bx0 = fminf(bx0, xi[k]);
+        bx1 = fmaxf(bx1, xi[k]);
+        by0 = fminf(by0, yi[k]);
+        by1 = fmaxf(by1, yi[k]);
+        rimax = fmaxf(rimax, ri[k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        bx0 = fminf(bx0, __shfl_xor(bx0, o));
+        bx1 = fmaxf(bx1, __shfl_xor(bx1, o));
+        by0 = fminf(by0, __shfl_xor(by0, o));
+        by1 = fmaxf(by1, __shfl_xor(by1, o));
+        rimax = fmaxf(rimax, __shfl_xor(rimax, o));
+    }
+    if ((tid & 63) == 0) {
+        float *r = red[tid >> 6];
+        r[0] = bx0;
+        r[1] = bx1;
+        r[2] = by0;
+        r[3] = by1;
+        r[4] = rimax;
     }
 
     const int jbeg = blockIdx.y * a.tiles_per_split * DS_TILE;
@@ -106,79 +311,58 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
     if (jend > a.n)
         jend = a.n;
     const int ntile = (jend - jbeg + DS_TILE - 1) / DS_TILE;
-    // a record that can never interact: zero mass, infinite cutoff
-    const float4 pad = make_float4(0.f, 0.f, 0.f, __builtin_inff());
+    // a record that cannot interact in either loop: zero mass, far away, infinite cutoff
+    const float4 pad = make_float4(1.0e15f, 1.0e15f, 0.f, __builtin_inff());
     constexpr int LPT = DS_TILE / DS_BLOCK;  // records each thread stages per tile
     float4 stage[LPT];
 
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
-        int j = jbeg + tid + l * DS_BLOCK;
+        const int j = jbeg + tid + l * DS_BLOCK;
         stage[l] = j < jend ? a.posm_cur[j] : pad;
     }
 #pragma unroll
     for (int l = 0; l < LPT; ++l)
         tile[0][tid + l * DS_BLOCK] = stage[l];
     __syncthreads();
+    bx0 = uniform_f(fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0])));
+    bx1 = uniform_f(fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1])));
+    by0 = uniform_f(fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2])));
+    by1 = uniform_f(fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])));
+    rimax = uniform_f(fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4])));
 
-    const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
     for (int t = 0; t < ntile; ++t) {
         const bool more = t + 1 < ntile;
         if (more) {
 #pragma unroll
             for (int l = 0; l < LPT; ++l) {
-                int j = jbeg + (t + 1) * DS_TILE + tid + l * DS_BLOCK;
+                const int j = jbeg + (t + 1) * DS_TILE + tid + l * DS_BLOCK;
                 stage[l] = j < jend ? a.posm_cur[j] : pad;
             }
         }
         const float4 *cur = tile[t & 1];
-        float fx[TPT], fy[TPT];
-#pragma unroll
-        for (int k = 0; k < TPT; ++k)
-            fx[k] = fy[k] = 0.f;
-#pragma unroll 8
-        for (int jj = 0; jj < DS_TILE; ++jj) {
-            const float4 b = cur[jj];
-#pragma unroll
-            for (int k = 0; k < TPT; ++k) {
-                float dx = b.x - xi[k];
-                float dy = b.y - yi[k];
-                float r2 = __builtin_fmaf(dx, dx, eps2);
-                r2 = __builtin_fmaf(dy, dy, r2);
-                float th = ri[k] + b.w;
-                float th2 = __builtin_fmaf(th, th, eps2);  // d^2 > th^2  <=>  d^2+eps^2 > th^2+eps^2
-                float s;
-                if (EXACT) {
-                    float r3 = r2 * __builtin_sqrtf(r2);
-                    s = b.z * __builtin_amdgcn_rcpf(r3 + eps3);
-                } else {
-                    float rinv = __builtin_amdgcn_rsqf(r2);
-                    s = (b.z * rinv) * (rinv * rinv);
-                }
-                // DirectSum::isCollide skips r_i + r_j + th >= dist (directSum.cpp:69-72)
-                bool pass = r2 > th2;
-                const bool amb = __builtin_fabsf(r2 - th2) <= th2 * DS_BAND;
-                if (__ballot(amb) != 0ull) {
-                    // Rare: the float distance is within its own rounding of the cutoff; decide
-                    // in FP64 on the FP64 positions as the reference does (vector.cpp:31-35).
-                    const int j = jbeg + t * DS_TILE + jj;
-                    if (amb && j < jend) {
-                        const double2 pj = a.pos_cur[j];
-                        const double2 pi = a.pos_cur[ti[k]];
-                        const double ex = pj.x - pi.x, ey = pj.y - pi.y;
-                        const double dist = sqrt(ex * ex + ey * ey);
-                        pass = !(a.radius[ti[k]] + a.radius[j] + a.collision_th >= dist) && j != ti[k];
-                    }
-                }
-                s = pass ? s : 0.f;
-                fx[k] = __builtin_fmaf(dx, s, fx[k]);
-                fy[k] = __builtin_fmaf(dy, s, fy[k]);
+        const int jt = jbeg + t * DS_TILE;
+#pragma unroll 1
+        for (int sub = 0; sub < DS_TILE / DS_SUB; ++sub) {
+            const int j0 = jt + sub * DS_SUB;
+            if (j0 >= jend)
+                break;
+            const SubMeta m = a.meta[j0 / DS_SUB];
+            const float gx = fmaxf(fmaxf(m.x0 - bx1, bx0 - m.x1), 0.f);
+            const float gy = fmaxf(fmaxf(m.y0 - by1, by0 - m.y1), 0.f);
+            const float lim = rimax + m.wmax;
+            // far: no pair of the two boxes can be inside the cutoff (a NaN anywhere means near)
+            const bool far = __builtin_fmaf(gx, gx, gy * gy) > lim * lim * DS_GAP_SLACK;
+            const bool uni = m.mu == m.mu;
+            const float4 *rec = cur + sub * DS_SUB;
+            if (far) {
+                if (uni)
+                    run_pairs<TPT, EXACT, false, true>(a, rec, j0, jend, m.mu, xi, yi, ri, ti, sx, sy);
+                else
+                    run_pairs<TPT, EXACT, false, false>(a, rec, j0, jend, 0.f, xi, yi, ri, ti, sx, sy);
+            } else {
+                run_pairs<TPT, EXACT, true, false>(a, rec, j0, jend, 0.f, xi, yi, ri, ti, sx, sy);
             }
-        }
-#pragma unroll
-        for (int k = 0; k < TPT; ++k) {
-            sx[k] += (double)fx[k];
-            sy[k] += (double)fy[k];
         }
         if (more) {
 #pragma unroll
@@ -190,7 +374,7 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
 
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
-        int i = tbase + tid + k * DS_BLOCK;
+        const int i = tbase + tid + k * DS_BLOCK;
         if (i >= tend)
             continue;
         if (a.jsplit == 1)
@@ -203,12 +387,12 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
 // Sums the jsplit partial accelerations of each target in split order, then integrates.
 __global__ __launch_bounds__(256) void k_direct_finish(DirectLaunch a)
 {
-    int i = a.t0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = a.t0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.t0 + a.nt)
         return;
     double sx = 0.0, sy = 0.0;
     for (int s = 0; s < a.jsplit; ++s) {
-        double2 p = a.part[(size_t)s * a.nt + (i - a.t0)];
+        const double2 p = a.part[(size_t)s * a.nt + (i - a.t0)];
         sx += p.x;
         sy += p.y;
     }
@@ -219,10 +403,10 @@ __global__ __launch_bounds__(256) void k_pack_posm(const double2 *pos, const dou
                                                    int i1, double inv_len, double inv_mass, double cth, float4 *posm,
                                                    float *rad)
 {
-    int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= i1)
         return;
-    double2 p = pos[i];
+    const double2 p = pos[i];
     posm[i] = make_float4((float)(p.x * inv_len), (float)(p.y * inv_len), (float)(mass[i] * inv_mass),
                           (float)((radius[i] + cth) * inv_len));
     rad[i] = (float)(radius[i] * inv_len);
@@ -233,7 +417,7 @@ int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const doubl
 {
     if (i1 <= i0)
         return NB_OK;
-    int blocks = (i1 - i0 + 255) / 256;
+    const int blocks = (i1 - i0 + 255) / 256;
     hipLaunchKernelGGL(k_pack_posm, dim3(blocks), dim3(256), 0, s, pos, mass, radius, i0, i1, inv_len_unit,
                        inv_mass_unit, collision_th, posm, rad);
     NB_HIP(hipGetLastError());
@@ -242,12 +426,14 @@ int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const doubl
 
 constexpr int DS_TPT = 2;
 
+size_t direct_meta_bytes(int n) { return sizeof(SubMeta) * (size_t)((n + DS_SUB - 1) / DS_SUB); }
+
 int direct_choose_jsplit(int n, int nt)
 {
     // Enough blocks to give every SIMD of the 256 CUs several waves: when the targets
     // alone do not, the source range is split across blockIdx.y.
-    int tb = (nt + DS_BLOCK * DS_TPT - 1) / (DS_BLOCK * DS_TPT);
-    int ntiles = (n + DS_TILE - 1) / DS_TILE;
+    const int tb = (nt + DS_BLOCK * DS_TPT - 1) / (DS_BLOCK * DS_TPT);
+    const int ntiles = (n + DS_TILE - 1) / DS_TILE;
     int want = (2048 + tb - 1) / tb;
     if (want > ntiles)
         want = ntiles;
@@ -261,7 +447,7 @@ int direct_choose_jsplit(int n, int nt)
 int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const float *rad, int n, int t0, int nt,
                 const ForceConsts &fc, const IntegrateArgs &ia, const uint8_t *dyn, const double2 *pos_cur,
                 double2 *pos_next, const double *radius, double collision_th, double2 *vel, double2 *acc,
-                double2 *part, int jsplit)
+                double2 *part, int jsplit, void *meta)
 {
     if (nt <= 0)
         return NB_OK;
@@ -275,6 +461,7 @@ int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const 
     a.pos_cur = pos_cur;
     a.pos_next = pos_next;
     a.radius = radius;
+    a.meta = (const SubMeta *)meta;
     a.collision_th = collision_th;
     a.vel = vel;
     a.acc = acc;
@@ -282,13 +469,15 @@ int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const 
     a.n = n;
     a.t0 = t0;
     a.nt = nt;
-    int ntiles = (n + DS_TILE - 1) / DS_TILE;
+    const int ntiles = (n + DS_TILE - 1) / DS_TILE;
     a.tiles_per_split = (ntiles + jsplit - 1) / jsplit;
     a.jsplit = (ntiles + a.tiles_per_split - 1) / a.tiles_per_split;  // no empty splits
     a.fc = fc;
     a.ia = ia;
     if (a.jsplit > 1 && !part)
         return fail(NB_ERR_ARG, "direct_step: split sources need a partial buffer");
+    const int nsub = (n + DS_SUB - 1) / DS_SUB;
+    hipLaunchKernelGGL(k_sub_meta, dim3((nsub + 3) / 4), dim3(256), 0, s, posm_cur, n, (SubMeta *)meta);
     dim3 grid((nt + DS_BLOCK * DS_TPT - 1) / (DS_BLOCK * DS_TPT), a.jsplit);
     if (fc.exact_denom)
         hipLaunchKernelGGL((k_direct<DS_TPT, true>), grid, dim3(DS_BLOCK), 0, s, a);

@@ -1,0 +1,102 @@
+"""One process per GPU: every rank holds all bodies, integrates its slice of the exchange
+order and all-gathers the new positions each step (RCCL over xGMI through
+torch.distributed's "nccl" backend; "gloo" on CPU tensors for the host-logic tests).
+
+The reference is single-GPU; this layer has no counterpart there.  The engine it drives
+only has to offer
+
+    n, set_partition(rank, world), step_local(), step_finish(),
+    exchange_tensor() -> torch tensor [world * chunk, 2] float64 holding every body's position,
+                         this rank's slice up to date after step_local()
+
+which NBodySim (below, through its exchange buffer) and the CPU test engine both do.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def slice_bounds(n, rank, world):
+    """Exchange-order slots [t0, t1) of a rank; chunk = ceil(n / world) (nb_set_partition)."""
+    chunk = (n + world - 1) // world
+    return min(n, rank * chunk), min(n, (rank + 1) * chunk), chunk
+
+
+class _DevicePointer:
+    """Exposes a raw device pointer to torch without copying."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {
+            "shape": (nbytes,),
+            "typestr": "|u1",
+            "data": (ptr, False),
+            "version": 2,
+        }
+
+
+def device_tensor(ptr, records, device):
+    """A float64 [records, 2] tensor aliasing `records` 16-byte position records at ptr."""
+    t = torch.as_tensor(_DevicePointer(ptr, records * 16), device=device)
+    return t.view(torch.float64).view(records, 2)
+
+
+class GpuEngine:
+    """NBodySim behind the engine protocol; its kernels run on torch's current stream."""
+
+    def __init__(self, sim, device):
+        self.sim = sim
+        self.n = sim.n
+        self.device = device
+        sim._lib.nb_set_stream(sim._h, torch.cuda.current_stream(device).cuda_stream)
+        self._cache = {}
+
+    def set_partition(self, rank, world):
+        self.sim.set_partition(rank, world)
+        self.world = world
+
+    def step_local(self):
+        self.sim.step_local()
+
+    def step_finish(self):
+        self.sim.step_finish()
+
+    def exchange_tensor(self):
+        ptr, chunk, rec = self.sim.exchange_buffer()
+        assert rec == 16
+        t = self._cache.get(ptr)
+        if t is None:
+            t = device_tensor(ptr, chunk * self.world, self.device)
+            self._cache[ptr] = t
+        return t
+
+
+class DistributedSim:
+    """Steps an engine across the ranks of a torch.distributed process group."""
+
+    def __init__(self, engine, group=None):
+        self.engine = engine
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.t0, self.t1, self.chunk = slice_bounds(engine.n, self.rank, self.world)
+        engine.set_partition(self.rank, self.world)
+
+    def all_gather_positions(self):
+        buf = self.engine.exchange_tensor()
+        mine = buf[self.rank * self.chunk:(self.rank + 1) * self.chunk]
+        if dist.get_backend(self.group) == "nccl":
+            # in place: every rank's slice already sits at its offset in the output
+            dist.all_gather_into_tensor(buf, mine, group=self.group)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine.clone(), group=self.group)
+            for r, p in enumerate(parts):
+                if r != self.rank:
+                    buf[r * self.chunk:(r + 1) * self.chunk].copy_(p)
+
+    def update(self, nsteps=1):
+        for _ in range(nsteps):
+            self.engine.step_local()
+            if self.world > 1:
+                self.all_gather_positions()
+            self.engine.step_finish()

@@ -1,0 +1,161 @@
+// main.cpp -- headless command-line program with the reference executables' argument
+// contracts (rendering is replaced by an optional binary dump):
+//
+//   BarnesHut <N> <Sim> <Iter>      src/gpu/BH/main.cu:86-117   (Sim 0 spiral 1 random 2 collision 3 solar)
+//   DirectSum <N> <Sim> <Iter>      src/gpu/DS/directSum_kernel.cu:258-312 (Sim 0 spiral 1 random 2 solar)
+//   nBodyCPU  <N> <Alg> <Sim>       src/cpu/main.cpp:79-122     (Alg 0 direct 1 Barnes-Hut; runs --iters steps)
+//
+// The program acts as the one it is invoked as (argv[0]); under any other name it is
+// BarnesHut unless --alg direct is given.  Exactly three positional arguments, or none for
+// the defaults (N 300, Sim 0, Iter 300), as in the reference; bad values print the reference's
+// message and return -1.  Additive flags: --alg bh|direct, --seed S, --theta T, --dump FILE,
+// --dump-every K, --iters K (nBodyCPU form), --quiet.
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "nbody_sim.hpp"
+
+namespace {
+
+// One frame: "NBDUMP1\0", n, step, then n records {x, y, vx, vy, mass} of doubles.  A frame
+// holds the full dynamical state, so it also serves as a checkpoint.
+void dump_frame(std::FILE *f, const nb_body *b, int n, int step)
+{
+    const char magic[8] = {'N', 'B', 'D', 'U', 'M', 'P', '1', 0};
+    const uint64_t hdr[2] = {(uint64_t)n, (uint64_t)step};
+    std::fwrite(magic, 1, 8, f);
+    std::fwrite(hdr, sizeof(uint64_t), 2, f);
+    std::vector<double> rec(5 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        rec[5 * (size_t)i + 0] = b[i].position.x;
+        rec[5 * (size_t)i + 1] = b[i].position.y;
+        rec[5 * (size_t)i + 2] = b[i].velocity.x;
+        rec[5 * (size_t)i + 3] = b[i].velocity.y;
+        rec[5 * (size_t)i + 4] = b[i].mass;
+    }
+    std::fwrite(rec.data(), sizeof(double), rec.size(), f);
+}
+
+// checkArgs, src/gpu/BH/main.cu:62-84
+bool checkArgs(int nBodies, int sim, int iter, int maxSim)
+{
+    if (nBodies < 1) {
+        std::cout << "ERROR: need to have at least 1 body" << std::endl;
+        return false;
+    }
+    if (sim < 0 || sim > maxSim) {
+        std::cout << "ERROR: simulation doesn't exist" << std::endl;
+        return false;
+    }
+    if (iter < 1) {
+        std::cout << "ERROR: need to have at least 1 iteration" << std::endl;
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    std::string prog = argv[0];
+    const size_t slash = prog.find_last_of('/');
+    if (slash != std::string::npos)
+        prog = prog.substr(slash + 1);
+    enum { BH, DS, CPU } mode = prog == "DirectSum" ? DS : prog == "nBodyCPU" ? CPU : BH;
+
+    int alg = mode == DS ? NB_ALG_DIRECT : NB_ALG_BARNES_HUT;
+    unsigned seed = 12345;
+    double theta = -1;
+    std::string dump;
+    int dump_every = 1, iters_flag = 300;
+    bool quiet = false;
+    std::vector<const char *> pos;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) {
+                std::cerr << name << " needs a value" << std::endl;
+                std::exit(-1);
+            }
+            return argv[++i];
+        };
+        if (a == "--alg") {
+            std::string v = next("--alg");
+            alg = v == "direct" ? NB_ALG_DIRECT : NB_ALG_BARNES_HUT;
+        } else if (a == "--seed")
+            seed = (unsigned)std::strtoul(next("--seed"), nullptr, 10);
+        else if (a == "--theta")
+            theta = std::atof(next("--theta"));
+        else if (a == "--dump")
+            dump = next("--dump");
+        else if (a == "--dump-every")
+            dump_every = std::atoi(next("--dump-every"));
+        else if (a == "--iters")
+            iters_flag = std::atoi(next("--iters"));
+        else if (a == "--quiet")
+            quiet = true;
+        else
+            pos.push_back(argv[i]);
+    }
+
+    int nBodies = mode == CPU ? 100 : 300;  // NUM_BODIES: cpu/constants.h:20, gpu/BH/constants.h:20
+    int sim = 0, iters = iters_flag;
+    if (pos.size() == 3) {
+        nBodies = std::atoi(pos[0]);
+        if (mode == CPU) {
+            alg = std::atoi(pos[1]) == 0 ? NB_ALG_DIRECT : NB_ALG_BARNES_HUT;
+            sim = std::atoi(pos[2]);
+        } else {
+            sim = std::atoi(pos[1]);
+            iters = std::atoi(pos[2]);
+        }
+    }
+    if (!checkArgs(nBodies, sim, iters, mode == BH ? 3 : 2))
+        return -1;
+    // the direct-sum and CPU programs number the solar system 2 (directSum_kernel.cu:274-286,
+    // cpu/nBody.cpp:29-41); the library uses the Barnes-Hut program's numbering
+    int scenario = sim;
+    if (mode != BH && sim == 2)
+        scenario = NB_SIM_SOLAR;
+    if (scenario == NB_SIM_SOLAR)
+        nBodies = 5;  // main.cu:101-102
+
+    nb_params params;
+    nb_default_params(&params);
+    if (theta >= 0)
+        params.theta = theta;
+    if (dump_every < 1)
+        dump_every = 1;
+
+    nbody::NBodySim nb(nBodies, alg, &params, seed);
+    nb.setup(scenario);
+    std::FILE *f = nullptr;
+    if (!dump.empty()) {
+        f = std::fopen(dump.c_str(), "wb");
+        if (!f) {
+            std::cerr << "cannot open " << dump << std::endl;
+            return EXIT_FAILURE;
+        }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) {
+        nb.update();
+        if (f && ((i + 1) % dump_every == 0 || i + 1 == iters)) {
+            nb.readDeviceBodies();
+            dump_frame(f, nb.getBodies(), nBodies, i + 1);
+        }
+    }
+    nb.sync();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (f)
+        std::fclose(f);
+    if (!quiet)
+        std::cout << (alg == NB_ALG_DIRECT ? "direct sum" : "Barnes-Hut") << " N=" << nBodies << " sim=" << sim
+                  << " iters=" << iters << " : " << ms / iters << " ms/step" << std::endl;
+    return 0;
+}

@@ -1,0 +1,56 @@
+// nbody_sim.hpp -- C++ host object over the C ABI (include/nbody.h), with the surface of the
+// reference's simulation classes so that a main() written against them ports line by line:
+//
+//   BarnesHutCuda(int n); setup(int sim); update(); readDeviceBodies(); getBodies()
+//       src/gpu/BH/barnesHutCuda.cuh:49-80
+//   NBody(int n, int alg, int sim); update(); bodies
+//       src/cpu/nBody.h:25-37
+//
+// Errors follow the reference's convention for its executables (src/gpu/BH/err.h:21-46):
+// print the message and exit(EXIT_FAILURE).
+#pragma once
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "nbody.h"
+
+namespace nbody {
+
+inline void check(int rc, const char *what)
+{
+    if (rc != NB_OK) {
+        std::fprintf(stderr, "nbody error at %s: %s\n", what, nb_last_error());
+        std::exit(EXIT_FAILURE);
+    }
+}
+
+class NBodySim {
+public:
+    NBodySim(int n, int alg, const nb_params *params = nullptr, unsigned seed = 12345)
+        : n_(n), seed_(seed), bodies_(n)
+    {
+        check(nb_create(params, n, alg, &sim_), "nb_create");
+    }
+    ~NBodySim() { nb_destroy(sim_); }
+    NBodySim(const NBodySim &) = delete;
+    NBodySim &operator=(const NBodySim &) = delete;
+
+    void setup(int sim) { check(nb_setup(sim_, sim, seed_), "nb_setup"); }
+    void setBodies(const nb_body *b) { check(nb_set_bodies(sim_, b, n_), "nb_set_bodies"); }
+    void update(int steps = 1) { check(nb_step(sim_, steps), "nb_step"); }
+    void readDeviceBodies() { check(nb_read_bodies(sim_, bodies_.data()), "nb_read_bodies"); }
+    nb_body *getBodies() { return bodies_.data(); }
+    void sync() { check(nb_sync(sim_), "nb_sync"); }
+    int size() const { return n_; }
+    nb_sim *handle() { return sim_; }
+
+private:
+    int n_;
+    unsigned seed_;
+    nb_sim *sim_ = nullptr;
+    std::vector<nb_body> bodies_;
+};
+
+}  // namespace nbody

@@ -28,6 +28,11 @@ def run_accel(nb, b, params=None):
     return sim, acc
 
 
+def exchange_bodies(sim, b):
+    """The bodies in the order the library holds them (its keys and indices refer to it)."""
+    return b[sim.order()]
+
+
 def tree_arrays(nb, sim):
     n = sim.n
     cap = 2 * n + 8
@@ -42,6 +47,8 @@ def tree_arrays(nb, sim):
 def test_bbox_keys_sort_are_bit_exact(nb, oracle, name):
     b = bodies_from_golden(golden(name))
     sim, _ = run_accel(nb, b)
+    assert np.array_equal(np.sort(sim.order()), np.arange(len(b)))
+    b = exchange_bodies(sim, b)
     box = sim.debug(nb.DBG_BBOX, np.float64, 4)
     assert np.array_equal(box, oracle.bh_bbox(b))
     keys = sim.debug(nb.DBG_KEYS, np.uint64, len(b))
@@ -57,6 +64,7 @@ def test_bbox_keys_sort_are_bit_exact(nb, oracle, name):
 def test_radix_sort_matches_cpu_stable_sort_large(nb, oracle, n):
     b = nb.init_scenario(nb.COLLISION, n, 5)
     sim, _ = run_accel(nb, b)
+    b = exchange_bodies(sim, b)
     box = sim.debug(nb.DBG_BBOX, np.float64, 4)
     assert np.array_equal(box, oracle.bh_bbox(b))
     ref_keys = oracle.morton_keys(b, box)
@@ -85,6 +93,7 @@ def test_tree_invariants_and_centre_of_mass(nb, name):
     b = bodies_from_golden(golden(name))
     n = len(b)
     sim, _ = run_accel(nb, b)
+    b = exchange_bodies(sim, b)
     ls, rng, ch, com = tree_arrays(nb, sim)
     keys = sim.debug(nb.DBG_SORTED_KEYS, np.uint64, n)
     idx = sim.debug(nb.DBG_SORTED_IDX, np.uint32, n)
@@ -256,3 +265,37 @@ def test_bh_close_to_direct_sum(nb, oracle):
     dyn = b["is_dynamic"] != 0
     assert np.median(rel_err(acc[dyn], oracle.direct_accel(b)[dyn])) < 2e-3
     sim.close()
+
+
+def test_two_rank_partition_equals_single_rank(nb, oracle):
+    """Each of two handles walks the tree only for its half of the bodies; positions are
+    exchanged through the exchange buffers as an all-gather would.  Every body's trajectory
+    must match the unpartitioned run to FP32 summation-order noise (the 64-body groups differ)."""
+    import ctypes as C
+
+    n = 5003
+    b = oracle.scenario(0, n, 8)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    with nb.NBodySim(n, nb.BARNES_HUT) as one, nb.NBodySim(n, nb.BARNES_HUT) as r0, nb.NBodySim(n, nb.BARNES_HUT) as r1:
+        for s in (one, r0, r1):
+            s.set_bodies(b)
+        r0.set_partition(0, 2)
+        r1.set_partition(1, 2)
+        for _ in range(5):
+            one.update()
+            for s in (r0, r1):
+                s.step_local()
+            for s in (r0, r1):
+                s.sync()
+            p0, chunk, rb = r0.exchange_buffer()
+            p1, _, _ = r1.exchange_buffer()
+            assert hip.hipMemcpy(p1, p0, chunk * rb, 3) == 0
+            assert hip.hipMemcpy(p0 + chunk * rb, p1 + chunk * rb, (n - chunk) * rb, 3) == 0
+            for s in (r0, r1):
+                s.step_finish()
+        ref = one.read_bodies()
+        a = r0.read_bodies()
+        c = r1.read_bodies()
+    assert np.array_equal(a["pos"], c["pos"])
+    assert np.linalg.norm(a["pos"] - ref["pos"], axis=1).max() <= 1e-9 * 5e11

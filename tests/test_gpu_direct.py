@@ -182,7 +182,8 @@ def _hip():
 
 def test_two_rank_partition_equals_single_rank(nb, oracle):
     """Two handles own half the targets each; positions are exchanged through the exchange
-    buffers as an all-gather would.  The result must equal the unpartitioned run bit for bit."""
+    buffers as an all-gather would.  The result must equal the unpartitioned run up to FP32
+    summation order (blocks hold different targets, so their near/far run choices differ)."""
     n = 3001
     b = oracle.scenario(0, n, 8)
     hip = _hip()
@@ -210,9 +211,12 @@ def test_two_rank_partition_equals_single_rank(nb, oracle):
         ref = one.read_bodies()
         a = r0.read_bodies()
         c = r1.read_bodies()
-    assert np.array_equal(a["pos"], ref["pos"]) and np.array_equal(c["pos"], ref["pos"])
-    assert np.array_equal(a["vel"][:chunk], ref["vel"][:chunk])
-    assert np.array_equal(c["vel"][chunk:], ref["vel"][chunk:])
+        order = r0.order()
+    assert np.array_equal(a["pos"], c["pos"])
+    assert np.linalg.norm(a["pos"] - ref["pos"], axis=1).max() <= 1e-9 * 5e11
+    own0, own1 = order[:chunk], order[chunk:]  # each rank keeps velocities of its own slots only
+    assert np.allclose(a["vel"][own0], ref["vel"][own0], rtol=1e-6, atol=1e-6)
+    assert np.allclose(c["vel"][own1], ref["vel"][own1], rtol=1e-6, atol=1e-6)
 
 
 def test_call_order_errors(nb):
