@@ -25,6 +25,7 @@ struct BhBuffers {
     uint32_t *idx[2] = {nullptr, nullptr};
     int sorted = 0;               // which of the two holds the sorted result
     uint32_t *hist = nullptr;     // 256 x sort blocks
+    uint32_t *hist_totals = nullptr;  // 256: keys per digit of the current pass
     int sort_blocks = 0;
     float4 *posm_s = nullptr;     // per sorted body {x, y, m, radius} in internal units
     uint4 *node_meta = nullptr;   // first body, body count, first child, child count | cell level << 8

@@ -261,12 +261,31 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *data, int count)
     (void)carry_sh;
 }
 
+// Sort pass, step 2: one block per digit.  Exclusive scan of the digit's per-block counts in
+// place (hist[d][0..nblk)), and the digit's total into totals[d].
+__global__ __launch_bounds__(256) void k_scan_rows(uint32_t *hist, int nblk, uint32_t *totals)
+{
+    uint32_t *row = hist + (size_t)blockIdx.x * nblk;
+    uint32_t running = 0;
+    for (int base = 0; base < nblk; base += 256) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblk ? (int)row[i] : 0;
+        int tile_total;
+        const int excl = block_excl_scan_256(v, tile_total);
+        if (i < nblk)
+            row[i] = running + (uint32_t)excl;
+        running += (uint32_t)tile_total;
+    }
+    if (threadIdx.x == 0)
+        totals[blockIdx.x] = running;
+}
+
 // Stable scatter of one 8-bit digit.  Wave w of a block owns a contiguous chunk of
 // 64*SORT_ITEMS keys and ranks them sub-round by sub-round against its own LDS counters
 // (no block barrier inside), so the order inside a digit is the input order.
 __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, const uint32_t *idx_in,
                                                       uint64_t *keys_out, uint32_t *idx_out, int n, int shift,
-                                                      const uint32_t *hist, int nblk)
+                                                      const uint32_t *hist, int nblk, const uint32_t *totals)
 {
     __shared__ uint32_t wcnt[4][SORT_BINS];
     __shared__ uint32_t dbase[SORT_BINS];
@@ -317,7 +336,10 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
             wcnt[k][tid] = run;
             run += c;
         }
-        dbase[tid] = hist[(size_t)tid * nblk + blockIdx.x];
+        // start of digit `tid` in the output = keys with a smaller digit (scan of the 256 totals)
+        int all;
+        const int before = block_excl_scan_256((int)totals[tid], all);
+        dbase[tid] = (uint32_t)before + hist[(size_t)tid * nblk + blockIdx.x];
     }
     __syncthreads();
 #pragma unroll
@@ -352,9 +374,9 @@ int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     int cur = 0;
     for (int shift = 0; shift < KEY_BITS; shift += SORT_BITS) {
         hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, s, b.keys[cur], n, shift, b.hist, nblk);
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, b.hist, SORT_BINS * nblk);
+        hipLaunchKernelGGL(k_scan_rows, dim3(SORT_BINS), dim3(256), 0, s, b.hist, nblk, b.hist_totals);
         hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, s, b.keys[cur], b.idx[cur], b.keys[cur ^ 1],
-                           b.idx[cur ^ 1], n, shift, b.hist, nblk);
+                           b.idx[cur ^ 1], n, shift, b.hist, nblk, b.hist_totals);
         cur ^= 1;
     }
     b.sorted = cur;
@@ -966,6 +988,7 @@ int bh_alloc(BhBuffers &b, int n)
         NB_TRY(dev_alloc(b.idx[k], (size_t)n));
     }
     NB_TRY(dev_alloc(b.hist, (size_t)SORT_BINS * b.sort_blocks));
+    NB_TRY(dev_alloc(b.hist_totals, SORT_BINS));
     NB_TRY(dev_alloc(b.posm_s, (size_t)n));
     NB_TRY(dev_alloc(b.node_meta, b.node_cap));
     NB_TRY(dev_alloc(b.split, (size_t)n + 256));
@@ -990,6 +1013,7 @@ void bh_free(BhBuffers &b)
         (void)hipFree(b.idx[k]);
     }
     (void)hipFree(b.hist);
+    (void)hipFree(b.hist_totals);
     (void)hipFree(b.posm_s);
     (void)hipFree(b.node_meta);
     (void)hipFree(b.split);
