@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 output of profiles/collect.sh (gpurun_out/prof_<round>/) into the
+committed summaries:
+
+    profiles/<round>_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary of `python3 bench.py`
+    profiles/<round>_bench.json           the JSON line that run printed
+    profiles/<round>_pmc.json             per-kernel averages of the counter passes
+    profiles/traffic.json                 HBM bytes per launch of the dominant kernels (read by bench.py)
+
+HBM bytes follow MI355X_MICROARCH.md's HBM section: FETCH_SIZE and WRITE_SIZE are in KiB; on
+gfx950 FETCH_SIZE reports half the bytes of a wide coalesced 16 B/lane stream.  The traversal's
+loads are 16 B/lane gathers whose calibration is unknown, so both the raw and the doubled figure
+are stored and the raw one is used as `traffic` (a lower bound).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = name.split("(")[0]
+    name = name.replace("void ", "").replace("nb::", "")
+    return name.strip()
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
+    out = os.path.join(ROOT, "profiles")
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats, os.path.join(out, rnd + "_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(out, rnd + "_bench.json"))
+    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    summary = {}
+    for k, cs in sorted(pmc.items()):
+        summary[k] = {c: {"launches": len(v), "mean": sum(v) / len(v), "max": max(v)} for c, v in sorted(cs.items())}
+        h, m = cs.get("TCC_HIT_sum"), cs.get("TCC_MISS_sum")
+        if h and m:
+            summary[k]["l2_hit_rate"] = sum(h) / (sum(h) + sum(m))
+    json.dump(summary, open(os.path.join(out, rnd + "_pmc.json"), "w"), indent=1, sort_keys=True)
+    traffic = {}
+    for k, tag in (("k_bh_force<false, false>", "k_bh_force"),):
+        if k in summary and "FETCH_SIZE" in summary[k] and "WRITE_SIZE" in summary[k]:
+            fetch = summary[k]["FETCH_SIZE"]["mean"] * 1024
+            write = summary[k]["WRITE_SIZE"]["mean"] * 1024
+            traffic[tag] = {
+                "hbm_bytes_per_launch": fetch + write,
+                "fetch_bytes_raw": fetch,
+                "fetch_bytes_if_halved_by_counter": 2 * fetch,
+                "write_bytes": write,
+                "l2_hit_rate": summary[k].get("l2_hit_rate"),
+                "workload": "galaxy collision N=5,000,000 (bench.py default)",
+                "round": rnd,
+            }
+    json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == "__main__":
+    main()
