@@ -36,7 +36,8 @@ struct BhBuffers {
                                   // or for a leaf minus its body's radius (sign bit set)
     float4 *node_rec = nullptr;   // traversal record {com.x, com.y, mass, w}: w = (width/theta)^2 for a
                                   // cell, -(radius + collision_th) for a leaf, internal units
-    uint2 *node_child = nullptr;  // first child, child count
+    uint2 *node_child = nullptr;  // x = first child << 3 | child count, y = float bits of the prune
+                                  // threshold: (collision_th - cell diagonal)^2, or -1
     uint32_t *tlist = nullptr;    // sorted positions of this rank's targets (multi-GPU), else unused
     uint32_t *tcount = nullptr;   // 1 entry: number of targets in tlist
     uint32_t *tblock = nullptr;   // per-block target counts (scratch of the compaction)

@@ -495,7 +495,6 @@ __global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, uint2 *nod
             meta.z = cf;
             meta.w = sp.w;
             node_meta[u] = meta;
-            node_child[u] = make_uint2(cf, (uint32_t)nchild);
             if (nchild) {
                 const uint32_t first = meta.x, end = meta.x + meta.y;
                 const uint32_t b0 = first, b1 = sp.x, b2 = sp.y, b3 = sp.z;
@@ -541,6 +540,7 @@ struct ComArgs {
     const double *box;
     double *node_com;
     float4 *node_rec;
+    uint2 *node_aux;
     double inv_len, inv_mass, theta, cth;
 };
 
@@ -553,6 +553,7 @@ __global__ __launch_bounds__(256) void k_com(ComArgs a, int d)
         const uint32_t nchild = meta.w & 0xffu;
         double cx, cy, mtot, width;
         float4 rec;
+        float prune = -1.f;
         if (nchild == 0) {
             // a leaf: one body, or several bodies with the same 62-bit path taken as one
             const uint32_t first = meta.x, count = meta.y;
@@ -604,6 +605,12 @@ __global__ __launch_bounds__(256) void k_com(ComArgs a, int d)
             const double wt = width * a.inv_len / a.theta;  // width / dist < theta  <=>  dist > width / theta
             rec = make_float4((float)(cx * a.inv_len), (float)(cy * a.inv_len), (float)(mtot * a.inv_mass),
                               (float)(wt * wt));
+            // Prune threshold: the cell's centre of mass lies inside the cell, so every point of
+            // the cell is within dist(com) + diagonal of a target.  If that is below collision_th
+            // (less a margin for float rounding) nothing in the cell can contribute.
+            const double height = ldexp(a.box[1] - a.box[3], -lvl);
+            const double reach = a.cth * (1.0 - 1.0e-4) - sqrt(width * width + height * height);
+            prune = reach > 0.0 ? (float)((reach * a.inv_len) * (reach * a.inv_len)) : -1.f;
         }
         double *o = a.node_com + 4 * (size_t)u;
         o[0] = cx;
@@ -611,6 +618,7 @@ __global__ __launch_bounds__(256) void k_com(ComArgs a, int d)
         o[2] = mtot;
         o[3] = width;
         a.node_rec[u] = rec;
+        a.node_aux[u] = make_uint2((meta.z << 3) | nchild, __float_as_uint(prune));
     }
 }
 
@@ -627,6 +635,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.box = b.box;
     c.node_com = b.node_com;
     c.node_rec = b.node_rec;
+    c.node_aux = b.node_child;
     c.inv_len = 1.0 / a.units.len_unit;
     c.inv_mass = 1.0 / a.units.mass_unit;
     c.theta = a.theta;
@@ -647,7 +656,7 @@ constexpr int TR_HIGH = TR_STACK - 100;   // above this the wave pops one node a
 struct ForceArgs {
     const float4 *posm_s;
     const float4 *node_rec;
-    const uint2 *node_child;
+    const uint2 *node_aux;   // x = first child << 3 | child count, y = float bits of the prune threshold
     const double *node_com;
     const uint32_t *idx;
     const uint32_t *tlist;   // may be null: targets are all sorted bodies
@@ -676,6 +685,24 @@ __device__ __forceinline__ float readlane_f(float v, int l)
 // 1e-6 of the distance; the band is several times that.
 constexpr float TR_BAND = 4.0e-5f;
 
+// The force of one accepted cell or body on the lane's target.
+template <bool EXACT>
+__device__ __forceinline__ void add_force(float dx, float dy, float d2, float nm, float eps2, float eps3, float &fx,
+                                          float &fy)
+{
+    const float r2 = d2 + eps2;
+    float s;
+    if (EXACT) {
+        const float r3 = r2 * __builtin_sqrtf(r2);
+        s = nm * __builtin_amdgcn_rcpf(r3 + eps3);
+    } else {
+        const float rinv = __builtin_amdgcn_rsqf(r2);
+        s = (nm * rinv) * (rinv * rinv);
+    }
+    fx = __builtin_fmaf(dx, s, fx);
+    fy = __builtin_fmaf(dy, s, fy);
+}
+
 template <bool EXACT, bool STATS>
 __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
 {
@@ -699,12 +726,18 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     const float thn = 2.f * ri + a.fc.cth;
     const float thn2 = thn * thn;
     const float thn2_band = thn2 * TR_BAND;
+    // cells whose opening distance exceeds every lane's drop distance need no drop test
+    float tmax = thn2 * (1.f + 4.f * TR_BAND);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+    const float thn2_max = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tmax)));
     const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
     const double2 pd = a.pos[body];
     const double rd = a.radius[body];
 
     double sx = 0.0, sy = 0.0;
-    unsigned long long n_eval = 0, n_acc = 0, n_recheck = 0;
+    unsigned long long n_eval = 0, n_acc = 0, n_recheck = 0, n_visit = 0;
 
     int top = 0;
     {
@@ -733,10 +766,10 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         }
         __builtin_amdgcn_wave_barrier();
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint2 ch = make_uint2(0u, 0u);
+        uint2 aux = make_uint2(0u, 0u);
         if (lane < c) {
             rec = a.node_rec[u];
-            ch = a.node_child[u];
+            aux = a.node_aux[u];
         }
         top = base;
         float fx = 0.f, fy = 0.f;
@@ -748,50 +781,58 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
             const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)um, j);
             const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(um >> 32), j);
             const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
-            const bool act = (mj >> lane) & 1ull;
+            const bool act = __builtin_amdgcn_inverse_ballot_w64(mj);
             const float dx = nx - xi, dy = ny - yi;
             const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-            const float r2 = d2 + eps2;
-            const bool leaf = __float_as_uint(nw) & 0x80000000u;  // wave-uniform
-            // primary threshold: the pair cutoff for a body, the opening distance for a cell
-            const float th = ri - nw;
-            const float t2 = leaf ? th * th : nw;
-            const float g = d2 - t2;
-            bool pass = leaf ? g >= 0.f : g > 0.f;  // body: not colliding; cell: accepted
-            bool far = true;                         // cell only: outside 2 r_i + th
-            bool amb = __builtin_fabsf(g) <= t2 * TR_BAND;
-            if (!leaf) {
-                const float g2 = d2 - thn2;
-                far = g2 >= 0.f;
-                amb = amb || (pass && __builtin_fabsf(g2) <= thn2_band);
-            }
-            if (__ballot(act && amb) != 0ull) {
-                // Rare: decide as the reference does, in FP64 on the FP64 positions
-                // (Vector::getDistance, vector.cpp:31-35).
-                const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
-                const double *nc = a.node_com + 4 * (size_t)uj;
-                const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
-                const double dist = sqrt(ex * ex + ey * ey);
-                const double wq = nc[3];
-                if (leaf) {
-                    pass = !(rd + (-wq) + a.collision_th > dist);
-                } else {
-                    pass = wq / dist < a.theta;
-                    far = !(rd * 2 + a.collision_th > dist);
-                }
-                if (STATS)
-                    n_recheck += 1;
-            }
             bool ok;
-            if (leaf) {
-                // the body itself has d2 == 0 (barnesHut.cpp:59 skips it by pointer)
+            if (__float_as_uint(nw) & 0x80000000u) {
+                // ---- a body: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
+                const float th = ri - nw;
+                const float t2 = th * th;
+                const float g = d2 - t2;
+                bool pass = g >= 0.f;
+                if (__ballot(act && __builtin_fabsf(g) <= t2 * TR_BAND) != 0ull) {
+                    // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
+                    const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
+                    const double *nc = a.node_com + 4 * (size_t)uj;
+                    const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
+                    const double dist = sqrt(ex * ex + ey * ey);
+                    pass = !(rd + (-nc[3]) + a.collision_th > dist);
+                    if (STATS)
+                        n_recheck += 1;
+                }
+                // the body itself has d2 == 0 (the reference skips it by pointer)
                 ok = act && pass && d2 > 0.f;
             } else {
-                ok = act && pass && far;
-                const uint64_t om = __ballot(act && !pass);
+                // ---- a cell: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
+                const float g = d2 - nw;
+                bool accept = g > 0.f;
+                bool far = true;  // outside 2 r_i + th of the centre of mass (barnesHut.cpp:75)
+                bool amb = __builtin_fabsf(g) <= nw * TR_BAND;
+                if (nw < thn2_max) {
+                    const float g2 = d2 - thn2;
+                    far = g2 >= 0.f;
+                    amb = amb || (accept && __builtin_fabsf(g2) <= thn2_band);
+                }
+                if (__ballot(act && amb) != 0ull) {
+                    const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
+                    const double *nc = a.node_com + 4 * (size_t)uj;
+                    const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
+                    const double dist = sqrt(ex * ex + ey * ey);
+                    accept = nc[3] / dist < a.theta;
+                    far = !(rd * 2 + a.collision_th > dist);
+                    if (STATS)
+                        n_recheck += 1;
+                }
+                ok = act && accept && far;
+                // Nothing below a cell that lies wholly inside the cutoff distance can contribute:
+                // every body and every centre of mass in it is closer than collision_th.  A lane
+                // that sees the cell that way does not open it.
+                const float prune = __int_as_float(__builtin_amdgcn_readlane((int)aux.y, j));
+                const uint64_t om = __ballot(act && !accept && !(d2 < prune));
                 if (om != 0ull) {
-                    const int cf = __builtin_amdgcn_readlane((int)ch.x, j);
-                    const int nc = __builtin_amdgcn_readlane((int)ch.y, j);
+                    const uint32_t packed = (uint32_t)__builtin_amdgcn_readlane((int)aux.x, j);
+                    const int cf = (int)(packed >> 3), nc = (int)(packed & 7u);
                     if (lane < nc) {
                         snode[top + lane] = (uint32_t)(cf + lane);
                         smask[top + lane] = om;
@@ -799,20 +840,15 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                     top += nc;
                 }
             }
-            float s;
-            if (EXACT) {
-                const float r3 = r2 * __builtin_sqrtf(r2);
-                s = nm * __builtin_amdgcn_rcpf(r3 + eps3);
-            } else {
-                const float rinv = __builtin_amdgcn_rsqf(r2);
-                s = (nm * rinv) * (rinv * rinv);
+            const uint64_t okm = __ballot(ok);
+            if (okm != 0ull) {
+                if (ok)
+                    add_force<EXACT>(dx, dy, d2, nm, eps2, eps3, fx, fy);
             }
-            s = ok ? s : 0.f;
-            fx = __builtin_fmaf(dx, s, fx);
-            fy = __builtin_fmaf(dy, s, fy);
             if (STATS) {
                 n_eval += (unsigned long long)__popcll(mj);
-                n_acc += (unsigned long long)__popcll(__ballot(ok));
+                n_acc += (unsigned long long)__popcll(okm);
+                n_visit += 1;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -824,6 +860,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         atomicAdd(&a.counters[0], n_eval);
         atomicAdd(&a.counters[1], n_acc);
         atomicAdd(&a.counters[4], n_recheck);
+        atomicAdd(&a.counters[5], n_visit);
     }
     if (!valid)
         return;
@@ -847,7 +884,6 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         a.pos[body] = p;
     }
 }
-
 
 // ---- targets of this rank (multi-GPU): sorted positions k whose body lies in [t0, t1) ----
 
@@ -914,7 +950,7 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     ForceArgs f;
     f.posm_s = b.posm_s;
     f.node_rec = b.node_rec;
-    f.node_child = b.node_child;
+    f.node_aux = b.node_child;
     f.node_com = b.node_com;
     f.radius = a.radius;
     f.theta = a.theta;
