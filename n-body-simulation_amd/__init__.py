@@ -21,7 +21,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnbody_hip.so")
+# NBODY_HIP_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("NBODY_HIP_LIB") or os.path.join(_HERE, "libnbody_hip.so")
 
 DIRECT, BARNES_HUT = 0, 1
 SPIRAL, RANDOM, COLLISION, SOLAR = 0, 1, 2, 3

@@ -317,8 +317,8 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
     chk(dev_alloc(s->dyn, s->cap));
     if (alg == NB_ALG_DIRECT) {
         chk(dev_alloc(s->pos2, s->cap));
-        chk(dev_alloc(s->posm[0], s->cap));
-        chk(dev_alloc(s->posm[1], s->cap));
+        chk(dev_alloc(s->posm[0], direct_record_capacity(n)));
+        chk(dev_alloc(s->posm[1], direct_record_capacity(n)));
         chk(dev_alloc(s->rad_s, s->cap));
         s->jsplit = direct_choose_jsplit(n, n);
         chk(dev_alloc(s->part, (size_t)s->jsplit * n));
@@ -394,8 +394,10 @@ int nb_set_bodies(nb_sim *s, const nb_body *b, int n)
         s->cur = 0;
         NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, 0, n, 1.0 / s->units.len_unit, 1.0 / s->units.mass_unit,
                          s->p.collision_th, s->posm[0], s->rad_s));
+        NB_TRY(pad_posm(s->stream, s->posm[0], n));
         // mass and cutoff radius never change: give the second buffer the same records
-        NB_HIP(hipMemcpyAsync(s->posm[1], s->posm[0], sizeof(float4) * n, hipMemcpyDeviceToDevice, s->stream));
+        NB_HIP(hipMemcpyAsync(s->posm[1], s->posm[0], sizeof(float4) * direct_record_capacity(n),
+                              hipMemcpyDeviceToDevice, s->stream));
     }
     NB_HIP(hipStreamSynchronize(s->stream));
     s->have_bodies = true;
@@ -522,6 +524,16 @@ int nb_set_partition(nb_sim *s, int rank, int world)
     s->chunk = ((size_t)s->n + world - 1) / world;
     s->t0 = (int)std::min((size_t)s->n, rank * s->chunk);
     s->t1 = (int)std::min((size_t)s->n, (rank + 1) * s->chunk);
+    if (s->alg == NB_ALG_DIRECT) {
+        // fewer targets per rank: split the sources further so the chip stays full
+        const int js = direct_choose_jsplit(s->n, s->t1 - s->t0);
+        if ((size_t)js * (size_t)(s->t1 - s->t0) > (size_t)s->jsplit * (size_t)s->n) {
+            (void)hipFree(s->part);
+            s->part = nullptr;
+            NB_TRY(dev_alloc(s->part, (size_t)js * (size_t)(s->t1 - s->t0)));
+        }
+        s->jsplit = js;
+    }
     return NB_OK;
 }
 

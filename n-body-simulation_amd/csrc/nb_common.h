@@ -62,6 +62,10 @@ int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const 
                 double2 *pos_next, const double *radius, double collision_th, double2 *vel, double2 *acc,
                 double2 *part, int jsplit, void *meta);
 int direct_choose_jsplit(int n, int nt);
+// Record arrays handed to direct_step hold direct_record_capacity(n) float4, the ones past n
+// written by pad_posm (the kernel stages whole tiles).
+size_t direct_record_capacity(int n);
+int pad_posm(hipStream_t s, float4 *posm, int n);
 // bytes of the per-run metadata scratch direct_step needs for n bodies
 size_t direct_meta_bytes(int n);
 

@@ -24,14 +24,29 @@
 //
 // Per interaction (2-D), far run: 2 sub, 2 fma, 1 rsq, 2-3 mul, 2 fma; near run: + add, fma,
 // cmp, select and the tie test.  Bound: FP32 vector ALU (no MFMA: no dense contraction here).
+#include <cstdlib>
+
 #include "nb_common.h"
 
 namespace nb {
 
+#ifndef NB_DS_TPT
+#define NB_DS_TPT 2  // targets per thread
+#endif
+#ifndef NB_DS_UNROLL
+#define NB_DS_UNROLL 16  // records per unrolled body of the pair loop
+#endif
+#ifndef NB_DS_DMA
+#define NB_DS_DMA 1  // 1: stage tiles with global_load_lds (no staging registers), 0: through registers
+#endif
+
 constexpr int DS_BLOCK = 256;
 constexpr int DS_TILE = 1024;  // records per LDS tile (16 KiB), two buffers
 constexpr int DS_SUB = 256;    // records per run with its own bounding box
-constexpr int DS_FLUSH = 32;   // pairs between FP32 -> FP64 folds
+#ifndef NB_DS_FLUSH
+#define NB_DS_FLUSH 32
+#endif
+constexpr int DS_FLUSH = NB_DS_FLUSH;   // pairs between FP32 -> FP64 folds
 // A float cutoff comparison closer than this fraction is repeated in FP64: the float distance
 // carries the coordinates' rounding (2^-24 of the domain each), a few 1e-6 of the cutoff.
 constexpr float DS_BAND = 4.0e-5f;
@@ -198,7 +213,7 @@ __device__ __forceinline__ void run_pairs(const DirectLaunch &a, const float4 *r
 #pragma unroll
         for (int k = 0; k < TPT; ++k)
             fx[k] = fy[k] = 0.f;
-#pragma unroll 8
+#pragma unroll NB_DS_UNROLL
         for (int jj = 0; jj < DS_FLUSH; ++jj) {
             const float4 b = rec[c + jj];
 #pragma unroll
@@ -252,26 +267,57 @@ __device__ __forceinline__ float uniform_f(float v)
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
+// Copies one tile of DS_TILE records (a multiple of the tile size is always readable: the
+// record arrays are padded with records that cannot interact) into LDS.
+__device__ __forceinline__ void stage_tile(const float4 *src, float4 *dst, int tid)
+{
+#if NB_DS_DMA
+    // global -> LDS without passing through registers: each wave instruction moves 64 x 16 B
+    // to a wave-uniform LDS base + lane * 16
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#pragma unroll
+    for (int l = 0; l < DS_TILE / DS_BLOCK; ++l) {
+        const int first = (l * (DS_BLOCK / 64) + wave) * 64;
+        __builtin_amdgcn_global_load_lds((const void *)(src + first + lane),
+                                         (__attribute__((address_space(3))) void *)(dst + first), 16, 0, 0);
+    }
+#else
+    float4 stage[DS_TILE / DS_BLOCK];
+#pragma unroll
+    for (int l = 0; l < DS_TILE / DS_BLOCK; ++l)
+        stage[l] = src[tid + l * DS_BLOCK];
+#pragma unroll
+    for (int l = 0; l < DS_TILE / DS_BLOCK; ++l)
+        dst[tid + l * DS_BLOCK] = stage[l];
+#endif
+}
+
 template <int TPT, bool EXACT>
 __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
 {
-    __shared__ float4 tile[2][DS_TILE];
+    __shared__ __attribute__((aligned(16))) float4 tile[2][DS_TILE];
     __shared__ float red[4][5];
     const int tid = threadIdx.x;
     const int tbase = a.t0 + blockIdx.x * (DS_BLOCK * TPT);
     const int tend = a.t0 + a.nt;
 
+    const int jbeg = blockIdx.y * a.tiles_per_split * DS_TILE;
+    int jend = jbeg + a.tiles_per_split * DS_TILE;
+    if (jend > a.n)
+        jend = a.n;
+    const int ntile = (jend - jbeg + DS_TILE - 1) / DS_TILE;
+    stage_tile(a.posm_cur + jbeg, tile[0], tid);
+
     float xi[TPT], yi[TPT], ri[TPT];
     int ti[TPT];
-    float4 self[TPT];
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
         const int i = tbase + tid + k * DS_BLOCK;
         // threads past the end work on a copy of the last target and discard the result
         ti[k] = i < tend ? i : tend - 1;
-        self[k] = a.posm_cur[ti[k]];
-        xi[k] = self[k].x;
-        yi[k] = self[k].y;
+        const float4 self = a.posm_cur[ti[k]];
+        xi[k] = self.x;
+        yi[k] = self.y;
         ri[k] = a.rad[ti[k]];
     }
     double sx[TPT], sy[TPT];
@@ -305,26 +351,7 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
         r[3] = by1;
         r[4] = rimax;
     }
-
-    const int jbeg = blockIdx.y * a.tiles_per_split * DS_TILE;
-    int jend = jbeg + a.tiles_per_split * DS_TILE;
-    if (jend > a.n)
-        jend = a.n;
-    const int ntile = (jend - jbeg + DS_TILE - 1) / DS_TILE;
-    // a record that cannot interact in either loop: zero mass, far away, infinite cutoff
-    const float4 pad = make_float4(1.0e15f, 1.0e15f, 0.f, __builtin_inff());
-    constexpr int LPT = DS_TILE / DS_BLOCK;  // records each thread stages per tile
-    float4 stage[LPT];
-
-#pragma unroll
-    for (int l = 0; l < LPT; ++l) {
-        const int j = jbeg + tid + l * DS_BLOCK;
-        stage[l] = j < jend ? a.posm_cur[j] : pad;
-    }
-#pragma unroll
-    for (int l = 0; l < LPT; ++l)
-        tile[0][tid + l * DS_BLOCK] = stage[l];
-    __syncthreads();
+    __syncthreads();  // also completes the staging of tile 0
     bx0 = uniform_f(fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0])));
     bx1 = uniform_f(fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1])));
     by0 = uniform_f(fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2])));
@@ -332,14 +359,8 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
     rimax = uniform_f(fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4])));
 
     for (int t = 0; t < ntile; ++t) {
-        const bool more = t + 1 < ntile;
-        if (more) {
-#pragma unroll
-            for (int l = 0; l < LPT; ++l) {
-                const int j = jbeg + (t + 1) * DS_TILE + tid + l * DS_BLOCK;
-                stage[l] = j < jend ? a.posm_cur[j] : pad;
-            }
-        }
+        if (t + 1 < ntile)
+            stage_tile(a.posm_cur + jbeg + (t + 1) * DS_TILE, tile[(t + 1) & 1], tid);
         const float4 *cur = tile[t & 1];
         const int jt = jbeg + t * DS_TILE;
 #pragma unroll 1
@@ -364,11 +385,8 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
                 run_pairs<TPT, EXACT, true, false>(a, rec, j0, jend, 0.f, xi, yi, ri, ti, sx, sy);
             }
         }
-        if (more) {
-#pragma unroll
-            for (int l = 0; l < LPT; ++l)
-                tile[(t + 1) & 1][tid + l * DS_BLOCK] = stage[l];
-        }
+        // the next tile has landed (the barrier waits for this wave's outstanding copies), and
+        // every wave is done reading the current one
         __syncthreads();
     }
 
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
         if (i >= tend)
             continue;
         if (a.jsplit == 1)
-            integrate_one(a, i, sx[k], sy[k], self[k]);
+            integrate_one(a, i, sx[k], sy[k], a.posm_cur[i]);
         else
             a.part[(size_t)blockIdx.y * a.nt + (i - a.t0)] = make_double2(sx[k], sy[k]);
     }
@@ -412,6 +430,25 @@ __global__ __launch_bounds__(256) void k_pack_posm(const double2 *pos, const dou
     rad[i] = (float)(radius[i] * inv_len);
 }
 
+// Records [n, cap) of a record array: zero mass, far away, infinite cutoff -- they cannot
+// interact in either pair loop, so whole tiles can be staged without a bounds test.
+__global__ __launch_bounds__(256) void k_pad_posm(float4 *posm, int n, int cap)
+{
+    const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap)
+        posm[i] = make_float4(1.0e15f, 1.0e15f, 0.f, __builtin_inff());
+}
+
+size_t direct_record_capacity(int n) { return ((size_t)n + DS_TILE - 1) / DS_TILE * DS_TILE + DS_TILE; }
+
+int pad_posm(hipStream_t s, float4 *posm, int n)
+{
+    const int cap = (int)direct_record_capacity(n);
+    hipLaunchKernelGGL(k_pad_posm, dim3((cap - n + 255) / 256), dim3(256), 0, s, posm, n, cap);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
 int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int i0, int i1,
               double inv_len_unit, double inv_mass_unit, double collision_th, float4 *posm, float *rad)
 {
@@ -424,23 +461,30 @@ int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const doubl
     return NB_OK;
 }
 
-constexpr int DS_TPT = 2;
+constexpr int DS_TPT = NB_DS_TPT;
 
 size_t direct_meta_bytes(int n) { return sizeof(SubMeta) * (size_t)((n + DS_SUB - 1) / DS_SUB); }
 
 int direct_choose_jsplit(int n, int nt)
 {
-    // Enough blocks to give every SIMD of the 256 CUs several waves: when the targets
-    // alone do not, the source range is split across blockIdx.y.
+    // The kernel is bound by vector-ALU issue, so the time of a launch is set by the busiest CU.
+    // Splitting the source range across blockIdx.y makes blocks many and short: ~65k blocks
+    // keep the 256 CUs within ~1 % of each other (measured: 1 split 4.4, 16 splits 5.0
+    // T interactions/s at N = 1M), and give small N enough waves to fill the chip at all.
     const int tb = (nt + DS_BLOCK * DS_TPT - 1) / (DS_BLOCK * DS_TPT);
     const int ntiles = (n + DS_TILE - 1) / DS_TILE;
-    int want = (2048 + tb - 1) / tb;
+    if (const char *e = getenv("NB_DS_JSPLIT"))  // tuning override
+        return atoi(e) < 1 ? 1 : (atoi(e) > ntiles ? ntiles : atoi(e));
+    int want = (65536 + tb - 1) / tb;
+    if (want > 64)
+        want = 64;
+    // partial sums: 16 B per target and split; stay below 1 GiB
+    while (want > 1 && (size_t)want * (size_t)nt * sizeof(double2) > ((size_t)1 << 30))
+        --want;
     if (want > ntiles)
         want = ntiles;
     if (want < 1)
         want = 1;
-    if (want > 64)
-        want = 64;
     return want;
 }
 
