@@ -91,7 +91,8 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
         torch.cuda.synchronize()
         c = sim.debug(nb.DBG_COUNTERS, np.uint64, 8)
         counters = {"node_evaluations": int(c[0]), "accepted_interactions": int(c[1]), "nodes": int(c[2]),
-                    "levels": int(c[3]), "fp64_redecisions": int(c[4]), "group_node_visits": int(c[5])}
+                    "levels": int(c[3]), "fp64_redecisions": int(c[4]), "group_node_visits": int(c[5]),
+                    "batches": int(c[6]), "max_stack": int(c[7])}
     elif alg == nb.BARNES_HUT and world > 1:
         step()  # keep the ranks' collectives matched with rank 0's extra step
     sim.close()

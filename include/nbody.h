@@ -161,7 +161,8 @@ enum nb_debug_array {
     NB_DBG_ORDER = 8,       /* n uint32: caller index of the body at each exchange-order slot */
     NB_DBG_COUNTERS = 9     /* 8 uint64: [0] body-node evaluations, [1] accepted interactions,
                                [2] nodes, [3] tree levels, [4] node visits re-decided in FP64,
-                               [5] node visits summed over the 64-body groups,
+                               [5] node visits summed over the 64-body groups, [6] node batches fetched,
+                               [7] deepest traversal stack,
                                of the last Barnes-Hut step run with stage timing on */
 };
 /* Copies the array into out (bytes = capacity of out); *written gets the size. */

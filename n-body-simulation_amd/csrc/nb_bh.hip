@@ -648,7 +648,10 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // ------------------------------------------------------------------ 6 traversal + integration
 
-constexpr int TR_STACK = 512;             // entries per wave
+#ifndef NB_TR_STACK
+#define NB_TR_STACK 512
+#endif
+constexpr int TR_STACK = NB_TR_STACK;     // entries per wave
 constexpr int TR_HIGH = TR_STACK - 100;   // above this the wave pops one node at a time: a
                                           // depth-first descent adds at most 3 entries per tree
                                           // level (< 32 levels), so the stack cannot overflow
@@ -737,11 +740,12 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     const double rd = a.radius[body];
 
     double sx = 0.0, sy = 0.0;
-    unsigned long long n_eval = 0, n_acc = 0, n_recheck = 0, n_visit = 0;
+    unsigned long long n_eval = 0, n_acc = 0, n_recheck = 0, n_visit = 0, n_batch = 0;
+    int max_top = 0;
 
     int top = 0;
     {
-        const uint64_t m0 = __ballot(dynamic);
+        const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
         if (m0 != 0ull) {
             if (lane == 0) {
                 snode[0] = 0u;
@@ -751,6 +755,10 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         }
     }
     while (top > 0) {
+        if (STATS) {
+            n_batch += 1;
+            max_top = top > max_top ? top : max_top;
+        }
         int c = top < 64 ? top : 64;
         int room = (TR_HIGH - top) / 3;
         if (room < 1)
@@ -773,6 +781,8 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         }
         top = base;
         float fx = 0.f, fy = 0.f;
+        // Per-lane conditions are kept as 64-bit lane masks in scalar registers (the result of a
+        // vector compare IS such a mask), so combining them costs scalar instructions only.
         for (int j = 0; j < c; ++j) {
             const float nx = readlane_f(rec.x, j);
             const float ny = readlane_f(rec.y, j);
@@ -780,56 +790,56 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
             const float nw = readlane_f(rec.w, j);
             const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)um, j);
             const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(um >> 32), j);
-            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
-            const bool act = __builtin_amdgcn_inverse_ballot_w64(mj);
+            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;  // lanes this node is visited for
             const float dx = nx - xi, dy = ny - yi;
             const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-            bool ok;
+            uint64_t okm;
             if (__float_as_uint(nw) & 0x80000000u) {
                 // ---- a body: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
                 const float th = ri - nw;
                 const float t2 = th * th;
                 const float g = d2 - t2;
-                bool pass = g >= 0.f;
-                if (__ballot(act && __builtin_fabsf(g) <= t2 * TR_BAND) != 0ull) {
+                uint64_t passm = __builtin_amdgcn_ballot_w64(g >= 0.f);
+                const uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= t2 * TR_BAND) & mj;
+                if (ambm != 0ull) {
                     // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
                     const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
                     const double *nc = a.node_com + 4 * (size_t)uj;
                     const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
                     const double dist = sqrt(ex * ex + ey * ey);
-                    pass = !(rd + (-nc[3]) + a.collision_th > dist);
+                    passm = __builtin_amdgcn_ballot_w64(!(rd + (-nc[3]) + a.collision_th > dist));
                     if (STATS)
                         n_recheck += 1;
                 }
                 // the body itself has d2 == 0 (the reference skips it by pointer)
-                ok = act && pass && d2 > 0.f;
+                okm = mj & passm & __builtin_amdgcn_ballot_w64(d2 > 0.f);
             } else {
                 // ---- a cell: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
                 const float g = d2 - nw;
-                bool accept = g > 0.f;
-                bool far = true;  // outside 2 r_i + th of the centre of mass (barnesHut.cpp:75)
-                bool amb = __builtin_fabsf(g) <= nw * TR_BAND;
+                uint64_t accm = __builtin_amdgcn_ballot_w64(g > 0.f);
+                uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= nw * TR_BAND);
+                uint64_t farm = ~0ull;  // outside 2 r_i + th of the centre of mass (barnesHut.cpp:75)
                 if (nw < thn2_max) {
                     const float g2 = d2 - thn2;
-                    far = g2 >= 0.f;
-                    amb = amb || (accept && __builtin_fabsf(g2) <= thn2_band);
+                    farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
+                    ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band) & accm;
                 }
-                if (__ballot(act && amb) != 0ull) {
+                if ((ambm & mj) != 0ull) {
                     const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
                     const double *nc = a.node_com + 4 * (size_t)uj;
                     const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
                     const double dist = sqrt(ex * ex + ey * ey);
-                    accept = nc[3] / dist < a.theta;
-                    far = !(rd * 2 + a.collision_th > dist);
+                    accm = __builtin_amdgcn_ballot_w64(nc[3] / dist < a.theta);
+                    farm = __builtin_amdgcn_ballot_w64(!(rd * 2 + a.collision_th > dist));
                     if (STATS)
                         n_recheck += 1;
                 }
-                ok = act && accept && far;
+                okm = mj & accm & farm;
                 // Nothing below a cell that lies wholly inside the cutoff distance can contribute:
                 // every body and every centre of mass in it is closer than collision_th.  A lane
                 // that sees the cell that way does not open it.
                 const float prune = __int_as_float(__builtin_amdgcn_readlane((int)aux.y, j));
-                const uint64_t om = __ballot(act && !accept && !(d2 < prune));
+                const uint64_t om = mj & ~accm & ~__builtin_amdgcn_ballot_w64(d2 < prune);
                 if (om != 0ull) {
                     const uint32_t packed = (uint32_t)__builtin_amdgcn_readlane((int)aux.x, j);
                     const int cf = (int)(packed >> 3), nc = (int)(packed & 7u);
@@ -840,9 +850,9 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                     top += nc;
                 }
             }
-            const uint64_t okm = __ballot(ok);
             if (okm != 0ull) {
-                if (ok)
+                asm volatile("" ::: "memory");  // keep the force arithmetic inside this branch
+                if (__builtin_amdgcn_inverse_ballot_w64(okm))
                     add_force<EXACT>(dx, dy, d2, nm, eps2, eps3, fx, fy);
             }
             if (STATS) {
@@ -861,6 +871,8 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         atomicAdd(&a.counters[1], n_acc);
         atomicAdd(&a.counters[4], n_recheck);
         atomicAdd(&a.counters[5], n_visit);
+        atomicAdd(&a.counters[6], n_batch);
+        atomicMax(&a.counters[7], (unsigned long long)max_top);
     }
     if (!valid)
         return;
