@@ -649,7 +649,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 // ------------------------------------------------------------------ 6 traversal + integration
 
 #ifndef NB_TR_STACK
-#define NB_TR_STACK 512
+#define NB_TR_STACK 384
 #endif
 constexpr int TR_STACK = NB_TR_STACK;     // entries per wave
 constexpr int TR_HIGH = TR_STACK - 100;   // above this the wave pops one node at a time: a
@@ -711,9 +711,12 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
 {
     __shared__ uint32_t st_node[4][TR_STACK];
     __shared__ uint64_t st_mask[4][TR_STACK];
+    // the batch being visited: per entry {record} and {lane mask, child word, prune threshold}
+    __shared__ __attribute__((aligned(16))) uint4 st_batch[4][64][2];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     uint32_t *snode = st_node[w];
     uint64_t *smask = st_mask[w];
+    uint4(*batch)[2] = st_batch[w];
 
     const int ntarget = a.tlist ? (int)*a.tcount : a.n;
     const int slot = (blockIdx.x * 4 + w) * 64 + lane;
@@ -735,6 +738,9 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     for (int o = 32; o > 0; o >>= 1)
         tmax = fmaxf(tmax, __shfl_xor(tmax, o));
     const float thn2_max = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tmax)));
+    // with a positive cutoff a body fails its own pair test (distance 0); only without one
+    // must the zero distance be excluded explicitly
+    const bool self_test = !(a.fc.cth > 0.f);
     const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
     const double2 pd = a.pos[body];
     const double rd = a.radius[body];
@@ -780,21 +786,32 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
             aux = a.node_aux[u];
         }
         top = base;
+        // Stage the batch in LDS: every lane then reads entry j with the same address (an LDS
+        // broadcast), which keeps the per-node data off the vector ALU's lane-read path.
+        batch[lane][0] = make_uint4(__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z),
+                                    __float_as_uint(rec.w));
+        batch[lane][1] = make_uint4((uint32_t)um, (uint32_t)(um >> 32), aux.x, aux.y);
+        __builtin_amdgcn_wave_barrier();
         float fx = 0.f, fy = 0.f;
+        uint4 nr = batch[0][0], nq = batch[0][1];
         // Per-lane conditions are kept as 64-bit lane masks in scalar registers (the result of a
         // vector compare IS such a mask), so combining them costs scalar instructions only.
         for (int j = 0; j < c; ++j) {
-            const float nx = readlane_f(rec.x, j);
-            const float ny = readlane_f(rec.y, j);
-            const float nm = readlane_f(rec.z, j);
-            const float nw = readlane_f(rec.w, j);
-            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)um, j);
-            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(um >> 32), j);
+            const uint4 r = nr, q = nq;
+            if (j + 1 < c) {
+                nr = batch[j + 1][0];
+                nq = batch[j + 1][1];
+            }
+            const float nx = __uint_as_float(r.x), ny = __uint_as_float(r.y), nm = __uint_as_float(r.z);
+            const float nw = __uint_as_float(r.w);
+            const uint32_t nwbits = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w);
+            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
+            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
             const uint64_t mj = ((uint64_t)mhi << 32) | mlo;  // lanes this node is visited for
             const float dx = nx - xi, dy = ny - yi;
             const float d2 = __builtin_fmaf(dy, dy, dx * dx);
             uint64_t okm;
-            if (__float_as_uint(nw) & 0x80000000u) {
+            if (nwbits & 0x80000000u) {
                 // ---- a body: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
                 const float th = ri - nw;
                 const float t2 = th * th;
@@ -811,15 +828,16 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                     if (STATS)
                         n_recheck += 1;
                 }
-                // the body itself has d2 == 0 (the reference skips it by pointer)
-                okm = mj & passm & __builtin_amdgcn_ballot_w64(d2 > 0.f);
+                okm = mj & passm;
+                if (self_test)  // the body itself has d2 == 0 (the reference skips it by pointer)
+                    okm &= __builtin_amdgcn_ballot_w64(d2 > 0.f);
             } else {
                 // ---- a cell: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
                 const float g = d2 - nw;
                 uint64_t accm = __builtin_amdgcn_ballot_w64(g > 0.f);
                 uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= nw * TR_BAND);
                 uint64_t farm = ~0ull;  // outside 2 r_i + th of the centre of mass (barnesHut.cpp:75)
-                if (nw < thn2_max) {
+                if (__uint_as_float(nwbits) < thn2_max) {
                     const float g2 = d2 - thn2;
                     farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
                     ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band) & accm;
@@ -838,10 +856,10 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                 // Nothing below a cell that lies wholly inside the cutoff distance can contribute:
                 // every body and every centre of mass in it is closer than collision_th.  A lane
                 // that sees the cell that way does not open it.
-                const float prune = __int_as_float(__builtin_amdgcn_readlane((int)aux.y, j));
+                const float prune = __uint_as_float(q.w);
                 const uint64_t om = mj & ~accm & ~__builtin_amdgcn_ballot_w64(d2 < prune);
                 if (om != 0ull) {
-                    const uint32_t packed = (uint32_t)__builtin_amdgcn_readlane((int)aux.x, j);
+                    const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
                     const int cf = (int)(packed >> 3), nc = (int)(packed & 7u);
                     if (lane < nc) {
                         snode[top + lane] = (uint32_t)(cf + lane);
