@@ -732,12 +732,6 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     const float thn = 2.f * ri + a.fc.cth;
     const float thn2 = thn * thn;
     const float thn2_band = thn2 * TR_BAND;
-    // cells whose opening distance exceeds every lane's drop distance need no drop test
-    float tmax = thn2 * (1.f + 4.f * TR_BAND);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        tmax = fmaxf(tmax, __shfl_xor(tmax, o));
-    const float thn2_max = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tmax)));
     // with a positive cutoff a body fails its own pair test (distance 0); only without one
     // must the zero distance be excluded explicitly
     const bool self_test = !(a.fc.cth > 0.f);
@@ -793,15 +787,12 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         batch[lane][1] = make_uint4((uint32_t)um, (uint32_t)(um >> 32), aux.x, aux.y);
         __builtin_amdgcn_wave_barrier();
         float fx = 0.f, fy = 0.f;
-        uint4 nr = batch[0][0], nq = batch[0][1];
         // Per-lane conditions are kept as 64-bit lane masks in scalar registers (the result of a
-        // vector compare IS such a mask), so combining them costs scalar instructions only.
+        // vector compare IS such a mask), so combining them costs scalar instructions only.  The
+        // one scalar unit of a CU serves all four SIMDs, so scalar instructions are the scarce
+        // resource of this loop: tests that are cheap in vector form are not branched around.
         for (int j = 0; j < c; ++j) {
-            const uint4 r = nr, q = nq;
-            if (j + 1 < c) {
-                nr = batch[j + 1][0];
-                nq = batch[j + 1][1];
-            }
+            const uint4 r = batch[j][0], q = batch[j][1];
             const float nx = __uint_as_float(r.x), ny = __uint_as_float(r.y), nm = __uint_as_float(r.z);
             const float nw = __uint_as_float(r.w);
             const uint32_t nwbits = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w);
@@ -817,7 +808,11 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                 const float t2 = th * th;
                 const float g = d2 - t2;
                 uint64_t passm = __builtin_amdgcn_ballot_w64(g >= 0.f);
+#ifdef NB_ABL_NOAMB
+                const uint64_t ambm = 0ull;
+#else
                 const uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= t2 * TR_BAND) & mj;
+#endif
                 if (ambm != 0ull) {
                     // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
                     const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
@@ -835,13 +830,17 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                 // ---- a cell: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
                 const float g = d2 - nw;
                 uint64_t accm = __builtin_amdgcn_ballot_w64(g > 0.f);
+#ifdef NB_ABL_NOAMB
+                uint64_t ambm = 0ull;
+#else
                 uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= nw * TR_BAND);
-                uint64_t farm = ~0ull;  // outside 2 r_i + th of the centre of mass (barnesHut.cpp:75)
-                if (__uint_as_float(nwbits) < thn2_max) {
-                    const float g2 = d2 - thn2;
-                    farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
-                    ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band) & accm;
-                }
+#endif
+                // outside 2 r_i + th of the centre of mass (barnesHut.cpp:75)
+                const float g2 = d2 - thn2;
+                uint64_t farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
+#ifndef NB_ABL_NOAMB
+                ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band) & accm;
+#endif
                 if ((ambm & mj) != 0ull) {
                     const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
                     const double *nc = a.node_com + 4 * (size_t)uj;
@@ -868,6 +867,9 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                     top += nc;
                 }
             }
+#ifdef NB_ABL_NOFORCE
+            okm = 0ull;
+#endif
             if (okm != 0ull) {
                 asm volatile("" ::: "memory");  // keep the force arithmetic inside this branch
                 if (__builtin_amdgcn_inverse_ballot_w64(okm))
