@@ -42,6 +42,8 @@ struct BhBuffers {
     uint32_t *tcount = nullptr;   // 1 entry: number of targets in tlist
     uint32_t *tblock = nullptr;   // per-block target counts (scratch of the compaction)
     unsigned long long *counters = nullptr;  // 8 statistics words
+    uint32_t *levels_host = nullptr;  // pinned host word: tree levels of the last finished step
+    int launched = 0;                 // levels the per-level build kernels were launched for
 };
 
 int bh_alloc(BhBuffers &b, int n);

@@ -416,18 +416,80 @@ __device__ __forceinline__ void level_chunk(const uint32_t *level_start, int d, 
         cend = m;
 }
 
-// First index in [lo, hi) whose digit at `shift` is >= c (digits are non-decreasing there).
-__device__ __forceinline__ uint32_t digit_lower_bound(const uint64_t *keys, uint32_t lo, uint32_t hi, int shift,
-                                                      uint32_t c)
+// Quadrant boundaries of a node's body range: the first indices in [first, end) whose digit at
+// `shift` is >= 1, >= 2, >= 3 (digits are non-decreasing there).  The three binary searches
+// advance in lockstep, so their dependent loads overlap.
+__device__ __forceinline__ void digit_boundaries(const uint64_t *keys, uint32_t first, uint32_t end, int shift,
+                                                 uint32_t &s1, uint32_t &s2, uint32_t &s3)
 {
-    while (lo < hi) {
-        uint32_t mid = lo + ((hi - lo) >> 1);
-        if (((uint32_t)(keys[mid] >> shift) & 3u) < c)
-            lo = mid + 1;
-        else
-            hi = mid;
+    uint32_t lo1 = first, hi1 = end, lo2 = first, hi2 = end, lo3 = first, hi3 = end;
+    while (lo1 < hi1 || lo2 < hi2 || lo3 < hi3) {
+        const uint32_t m1 = lo1 + ((hi1 - lo1) >> 1), m2 = lo2 + ((hi2 - lo2) >> 1), m3 = lo3 + ((hi3 - lo3) >> 1);
+        const uint32_t d1 = lo1 < hi1 ? (uint32_t)(keys[m1] >> shift) & 3u : 0u;
+        const uint32_t d2 = lo2 < hi2 ? (uint32_t)(keys[m2] >> shift) & 3u : 0u;
+        const uint32_t d3 = lo3 < hi3 ? (uint32_t)(keys[m3] >> shift) & 3u : 0u;
+        if (lo1 < hi1) {
+            if (d1 < 1u)
+                lo1 = m1 + 1;
+            else
+                hi1 = m1;
+        }
+        if (lo2 < hi2) {
+            if (d2 < 2u)
+                lo2 = m2 + 1;
+            else
+                hi2 = m2;
+        }
+        if (lo3 < hi3) {
+            if (d3 < 3u)
+                lo3 = m3 + 1;
+            else
+                hi3 = m3;
+        }
     }
-    return lo;
+    s1 = lo1;
+    s2 = lo2;
+    s3 = lo3;
+}
+
+// What a node becomes: its quadrant boundaries and child count | cell level << 8 (0 children for
+// a leaf: one body, or several bodies with one key).
+__device__ __forceinline__ uint4 classify_node(const uint64_t *keys, uint4 meta)
+{
+    const uint32_t first = meta.x, count = meta.y, last = first + count - 1;
+    const uint64_t kf = keys[first], kl = keys[last];
+    if (count <= 1 || kf == kl)
+        return make_uint4(0u, 0u, 0u, 0u);
+    // level of the smallest cell holding the whole range: the first differing digit
+    const int lvl = (__clzll((long long)(kf ^ kl)) - 2) >> 1;
+    const int shift = KEY_BITS - 2 - 2 * lvl;
+    const uint32_t end = first + count;
+    uint32_t s1, s2, s3;
+    digit_boundaries(keys, first, end, shift, s1, s2, s3);
+    const uint32_t nchild = (s1 > first) + (s2 > s1) + (s3 > s2) + (end > s3);
+    return make_uint4(s1, s2, s3, nchild | ((uint32_t)lvl << 8));
+}
+
+// Writes a node's final metadata and the ranges of its children starting at slot cf.
+__device__ __forceinline__ void emit_children(uint4 *node_meta, uint32_t u, uint4 sp, uint32_t cf)
+{
+    uint4 meta = node_meta[u];
+    meta.z = cf;
+    meta.w = sp.w;
+    node_meta[u] = meta;
+    if (sp.w & 0xffu) {
+        const uint32_t first = meta.x, end = meta.x + meta.y;
+        const uint32_t b0 = first, b1 = sp.x, b2 = sp.y, b3 = sp.z;
+        uint32_t c = cf;
+        if (b1 > b0)
+            node_meta[c++] = make_uint4(b0, b1 - b0, 0u, 0u);
+        if (b2 > b1)
+            node_meta[c++] = make_uint4(b1, b2 - b1, 0u, 0u);
+        if (b3 > b2)
+            node_meta[c++] = make_uint4(b2, b3 - b2, 0u, 0u);
+        if (end > b3)
+            node_meta[c++] = make_uint4(b3, end - b3, 0u, 0u);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4 *node_meta, uint4 *split,
@@ -437,22 +499,8 @@ __global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4
     level_chunk(level_start, d, lbeg, m, cbeg, cend);
     int local = 0;
     for (uint32_t slot = cbeg + threadIdx.x; slot < cend; slot += 256) {
-        const uint4 meta = node_meta[lbeg + slot];
-        const uint32_t first = meta.x, count = meta.y, last = first + count - 1;
-        uint4 sp = make_uint4(0u, 0u, 0u, 0u);
-        const uint64_t kf = keys[first], kl = keys[last];
-        if (count > 1 && kf != kl) {
-            // level of the smallest cell holding the whole range: the first differing digit
-            const int lvl = (__clzll((long long)(kf ^ kl)) - 2) >> 1;
-            const int shift = KEY_BITS - 2 - 2 * lvl;
-            const uint32_t end = first + count;
-            const uint32_t s1 = digit_lower_bound(keys, first, end, shift, 1u);
-            const uint32_t s2 = digit_lower_bound(keys, s1, end, shift, 2u);
-            const uint32_t s3 = digit_lower_bound(keys, s2, end, shift, 3u);
-            const uint32_t nchild = (s1 > first) + (s2 > s1) + (s3 > s2) + (end > s3);
-            sp = make_uint4(s1, s2, s3, nchild | ((uint32_t)lvl << 8));
-            local += (int)nchild;
-        }
+        const uint4 sp = classify_node(keys, node_meta[lbeg + slot]);
+        local += (int)(sp.w & 0xffu);
         split[slot] = sp;
     }
     const int tot = block_sum_256(local);
@@ -488,41 +536,68 @@ __global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, uint2 *nod
         const int nchild = (int)(sp.w & 0xffu);
         int tile_total;
         const int excl = block_excl_scan_256(nchild, tile_total);
-        if (valid) {
-            const uint32_t u = lbeg + slot;
-            uint4 meta = node_meta[u];
-            const uint32_t cf = running + (uint32_t)excl;
-            meta.z = cf;
-            meta.w = sp.w;
-            node_meta[u] = meta;
-            if (nchild) {
-                const uint32_t first = meta.x, end = meta.x + meta.y;
-                const uint32_t b0 = first, b1 = sp.x, b2 = sp.y, b3 = sp.z;
-                uint32_t c = cf;
-                if (b1 > b0)
-                    node_meta[c++] = make_uint4(b0, b1 - b0, 0u, 0u);
-                if (b2 > b1)
-                    node_meta[c++] = make_uint4(b1, b2 - b1, 0u, 0u);
-                if (b3 > b2)
-                    node_meta[c++] = make_uint4(b2, b3 - b2, 0u, 0u);
-                if (end > b3)
-                    node_meta[c++] = make_uint4(b3, end - b3, 0u, 0u);
-            }
-        }
+        if (valid)
+            emit_children(node_meta, lbeg + slot, sp, running + (uint32_t)excl);
         running += (uint32_t)tile_total;
     }
+}
+
+// Levels from d0 on, by ONE block: the host launches the per-level kernels only for as many
+// levels as the previous steps' trees had (plus a margin) and lets this kernel finish whatever
+// is left -- normally nothing, so it returns at once; a tree that grew deeper is still built
+// completely, just by fewer threads.
+__global__ __launch_bounds__(256) void k_build_tail(const uint64_t *keys, uint4 *node_meta, uint4 *split,
+                                                    uint32_t *level_start, int d0)
+{
+    for (int d = d0; d < BH_MAX_DEPTH - 2; ++d) {
+        const uint32_t lbeg = level_start[d], m = level_start[d + 1] - lbeg;
+        if (m == 0)
+            break;  // uniform: every thread reads the same words
+        uint32_t running = level_start[d + 1];
+        for (uint32_t tile = 0; tile < m; tile += 256) {
+            const uint32_t slot = tile + threadIdx.x;
+            uint4 sp = make_uint4(0u, 0u, 0u, 0u);
+            if (slot < m)
+                sp = classify_node(keys, node_meta[lbeg + slot]);
+            int tile_total;
+            const int excl = block_excl_scan_256((int)(sp.w & 0xffu), tile_total);
+            if (slot < m)
+                emit_children(node_meta, lbeg + slot, sp, running + (uint32_t)excl);
+            running += (uint32_t)tile_total;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            level_start[d + 2] = running;
+        __threadfence_block();
+        __syncthreads();
+    }
+    (void)split;
+}
+
+// Tree levels the per-level kernels are launched for: what the last finished step needed (the
+// device leaves that number in host-visible memory; reading a stale one only costs speed) plus a
+// margin, everything on the first steps.
+static int launched_levels(const BhBuffers &b)
+{
+    const uint32_t seen = b.levels_host ? *(volatile uint32_t *)b.levels_host : 0u;
+    int l = seen == 0u ? BH_MAX_DEPTH - 2 : (int)seen + 2;
+    if (l > BH_MAX_DEPTH - 2)
+        l = BH_MAX_DEPTH - 2;
+    return l;
 }
 
 int bh_build(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     const uint64_t *keys = b.keys[b.sorted];
     hipLaunchKernelGGL(k_build_init, dim3(1), dim3(64), 0, s, b.node_meta, b.level_start, a.n, b.counters);
-    for (int d = 0; d < BH_MAX_DEPTH - 2; ++d) {
+    b.launched = launched_levels(b);
+    for (int d = 0; d < b.launched; ++d) {
         hipLaunchKernelGGL(k_build_count, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, keys, b.node_meta, b.split,
                            b.level_start, b.bsum, d);
         hipLaunchKernelGGL(k_build_emit, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, b.node_meta, b.node_child, b.split,
                            b.level_start, b.bsum, d);
     }
+    hipLaunchKernelGGL(k_build_tail, dim3(1), dim3(256), 0, s, keys, b.node_meta, b.split, b.level_start, b.launched);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -544,7 +619,9 @@ struct ComArgs {
     double inv_len, inv_mass, theta, cth;
 };
 
-__global__ __launch_bounds__(256) void k_com(ComArgs a, int d)
+// Centres of mass, masses and traversal records of the nodes of tree level d (children first:
+// the caller goes through the levels bottom-up).
+__device__ __forceinline__ void com_level(const ComArgs &a, int d)
 {
     const uint32_t lbeg = a.level_start[d], lend = a.level_start[d + 1];
     const double width0 = a.box[2] - a.box[0];  // QuadTree::getWidth of the root (quadtree.cpp:234-237)
@@ -622,6 +699,23 @@ __global__ __launch_bounds__(256) void k_com(ComArgs a, int d)
     }
 }
 
+// d_hi == d + 1: level d by the whole grid.  d_hi > d + 1: levels d_hi-1 down to d by ONE block
+// in one launch (the levels past the ones the host expects to exist, normally empty).
+__global__ __launch_bounds__(256) void k_com(ComArgs a, int d, int d_hi)
+{
+    if (d_hi > d + 1) {
+        for (int dd = d_hi - 1; dd >= d; --dd) {
+            if (a.level_start[dd + 1] > a.level_start[dd]) {  // uniform
+                com_level(a, dd);
+                __threadfence_block();
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    com_level(a, d);
+}
+
 int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     ComArgs c;
@@ -640,8 +734,11 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.inv_mass = 1.0 / a.units.mass_unit;
     c.theta = a.theta;
     c.cth = a.collision_th;
-    for (int d = BH_MAX_DEPTH - 2; d >= 0; --d)
-        hipLaunchKernelGGL(k_com, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, c, d);
+    // levels beyond the ones the build launched per-level kernels for: one block, one launch
+    if (b.launched < BH_MAX_DEPTH - 1)
+        hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
+    for (int d = b.launched - 1; d >= 0; --d)
+        hipLaunchKernelGGL(k_com, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, c, d, d + 1);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -965,7 +1062,8 @@ __global__ __launch_bounds__(256) void k_tl_emit(const uint32_t *idx, int n, uin
         *tcount = (uint32_t)pos;
 }
 
-__global__ void k_bh_finish_counters(const uint32_t *level_start, unsigned long long *counters)
+__global__ void k_bh_finish_counters(const uint32_t *level_start, unsigned long long *counters,
+                                     uint32_t *levels_host)
 {
     if (threadIdx.x == 0) {
         int levels = 0;
@@ -974,6 +1072,8 @@ __global__ void k_bh_finish_counters(const uint32_t *level_start, unsigned long 
                 levels = d + 1;
         counters[2] = level_start[levels];
         counters[3] = (unsigned long long)levels;
+        if (levels_host)
+            *levels_host = (uint32_t)levels;  // host-visible: sizes the next steps' launches
     }
 }
 
@@ -1020,13 +1120,13 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
             hipLaunchKernelGGL((k_bh_force<true, true>), grid, dim3(256), 0, s, f);
         else
             hipLaunchKernelGGL((k_bh_force<false, true>), grid, dim3(256), 0, s, f);
-        hipLaunchKernelGGL(k_bh_finish_counters, dim3(1), dim3(64), 0, s, b.level_start, b.counters);
     } else {
         if (a.fc.exact_denom)
             hipLaunchKernelGGL((k_bh_force<true, false>), grid, dim3(256), 0, s, f);
         else
             hipLaunchKernelGGL((k_bh_force<false, false>), grid, dim3(256), 0, s, f);
     }
+    hipLaunchKernelGGL(k_bh_finish_counters, dim3(1), dim3(64), 0, s, b.level_start, b.counters, b.levels_host);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -1069,6 +1169,13 @@ int bh_alloc(BhBuffers &b, int n)
     NB_TRY(dev_alloc(b.tcount, 4));
     NB_TRY(dev_alloc(b.tblock, (size_t)(n + TL_TILE - 1) / TL_TILE + 1));
     NB_TRY(dev_alloc(b.counters, 8));
+    {
+        void *h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
+            return fail(NB_ERR_NOMEM, "hipHostMalloc failed");
+        b.levels_host = (uint32_t *)h;
+        *b.levels_host = 0u;
+    }
     return NB_OK;
 }
 
@@ -1094,6 +1201,8 @@ void bh_free(BhBuffers &b)
     (void)hipFree(b.tcount);
     (void)hipFree(b.tblock);
     (void)hipFree(b.counters);
+    if (b.levels_host)
+        (void)hipHostFree(b.levels_host);
     b = BhBuffers();
 }
 

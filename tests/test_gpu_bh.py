@@ -299,3 +299,32 @@ def test_two_rank_partition_equals_single_rank(nb, oracle):
         c = r1.read_bodies()
     assert np.array_equal(a["pos"], c["pos"])
     assert np.linalg.norm(a["pos"] - ref["pos"], axis=1).max() <= 1e-9 * 5e11
+
+
+def test_tree_deeper_than_the_previous_steps(nb, oracle):
+    """The per-level build kernels are launched for as many levels as earlier trees had; a tree
+    that suddenly needs many more levels (here: a tight clump replaces a spread-out disc) must
+    still be built completely and give the reference's accelerations."""
+    n = 3000
+    wide = oracle.scenario(0, n, 12)
+    with nb.NBodySim(n, nb.BARNES_HUT) as sim:
+        sim.set_bodies(wide)
+        sim.set_stage_timing(True)
+        sim.update(3)
+        shallow = int(sim.debug(nb.DBG_COUNTERS, np.uint64, 8)[3])
+        tight = wide.copy()
+        # a geometric sequence of bodies converging on a point: every cell level splits one body
+        # off, a caterpillar ~26 levels deep (a clump would only add a collapsed chain)
+        k = np.arange(26)
+        tight["pos"][:26] = np.array([3.3e11, -2.1e11]) + 1.0e11 * 0.5 ** k[:, None] * np.array([1.0, 0.7])
+        sim.set_bodies(tight)
+        acc = sim.compute_accel()
+        deep = int(sim.debug(nb.DBG_COUNTERS, np.uint64, 8)[3])
+        assert deep >= shallow + 8
+        ref = oracle.bh_accel(tight)
+        dyn = tight["is_dynamic"] != 0
+        assert rel_err(acc[dyn], ref[dyn]).max() <= ACC_EXPECTED
+        # and back to a shallow tree
+        sim.set_bodies(wide)
+        acc = sim.compute_accel()
+        assert rel_err(acc[dyn], oracle.bh_accel(wide)[dyn]).max() <= ACC_EXPECTED
