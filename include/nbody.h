@@ -87,7 +87,15 @@ typedef struct nb_params {
     double theta;         /* THETA        0.5 (Barnes-Hut opening ratio, cell x-width / distance) */
     double collision_th;  /* COLLISION_TH 1.0e10: pairs closer than r_i + r_j + this are skipped */
     double bbox_margin;   /* the 1.0e10 pad added round the bounding box (barnesHut.cpp:28-31) */
+    int integrator;       /* nb_integrator; 0 = the reference's scheme */
+    int reserved_;
 } nb_params;
+
+/* NB_INT_EULER is the reference's update (v += a dt, then x += v dt: semi-implicit Euler,
+ * directSum.cpp:49-67).  NB_INT_LEAPFROG is kick-drift-kick with the same single force
+ * evaluation per step: the first step kicks by dt/2, later steps by dt, and nb_read_bodies
+ * returns velocities brought to the positions' time (v + a(x) dt/2). */
+enum nb_integrator { NB_INT_EULER = 0, NB_INT_LEAPFROG = 1 };
 
 typedef struct nb_sim nb_sim; /* opaque */
 
@@ -174,6 +182,12 @@ int nb_debug_read(nb_sim *sim, int which, void *out, size_t bytes, size_t *writt
  * [0] bbox [1] keys [2] sort [3] build [4] com [5] force+integrate [6] other. */
 int nb_set_stage_timing(nb_sim *sim, int on);
 int nb_stage_ms(nb_sim *sim, float *out, int count);
+
+/* Conserved quantities of the current state, computed in FP64 (not part of the hot path):
+ * out[0] total mass, [1..2] centre of mass, [3..4] momentum, [5] angular momentum about the
+ * origin, [6] kinetic energy, [7] potential energy -G sum_{i<j} m_i m_j / sqrt(d^2 + eps^2) over
+ * the pairs the force law does not skip (NaN when n > 131072: it is an O(n^2) sum). */
+int nb_diagnostics(nb_sim *sim, double *out, int count);
 
 const char *nb_last_error(void);
 const char *nb_version(void);

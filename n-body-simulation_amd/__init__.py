@@ -26,6 +26,7 @@ LIB_PATH = os.environ.get("NBODY_HIP_LIB") or os.path.join(_HERE, "libnbody_hip.
 
 DIRECT, BARNES_HUT = 0, 1
 SPIRAL, RANDOM, COLLISION, SOLAR = 0, 1, 2, 3
+EULER, LEAPFROG = 0, 1
 
 # Same 72-byte layout as the reference's Body.
 BODY_DTYPE = np.dtype(
@@ -45,7 +46,7 @@ ABI_SYMBOLS = [
     "nb_default_params", "nb_init_scenario", "nb_create", "nb_destroy", "nb_setup", "nb_set_bodies",
     "nb_step", "nb_compute_accel", "nb_read_bodies", "nb_sync", "nb_set_stream", "nb_set_partition",
     "nb_exchange_buffer", "nb_step_local", "nb_step_finish", "nb_debug_read", "nb_set_stage_timing",
-    "nb_stage_ms", "nb_last_error", "nb_version",
+    "nb_stage_ms", "nb_diagnostics", "nb_last_error", "nb_version",
 ]
 
 
@@ -57,6 +58,8 @@ class Params(C.Structure):
         ("theta", C.c_double),
         ("collision_th", C.c_double),
         ("bbox_margin", C.c_double),
+        ("integrator", C.c_int),
+        ("reserved_", C.c_int),
     ]
 
 
@@ -99,6 +102,7 @@ def load_library(path=None):
     lib.nb_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.nb_set_stage_timing.argtypes = [vp, i]
     lib.nb_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]
+    lib.nb_diagnostics.argtypes = [vp, C.POINTER(C.c_double), i]
     lib.nb_last_error.restype = C.c_char_p
     lib.nb_version.restype = C.c_char_p
     for name in ABI_SYMBOLS:
@@ -202,6 +206,13 @@ class NBodySim:
         _check(self._lib.nb_stage_ms(self._h, out, 8))
         names = ["bbox", "keys", "sort", "build", "com", "force", "other"]
         return {k: out[i] for i, k in enumerate(names)}
+
+    def diagnostics(self):
+        """Conserved quantities of the current state (FP64); potential is NaN above 131072 bodies."""
+        out = (C.c_double * 8)()
+        _check(self._lib.nb_diagnostics(self._h, out, 8))
+        return {"mass": out[0], "com": (out[1], out[2]), "momentum": (out[3], out[4]), "angular_momentum": out[5],
+                "kinetic": out[6], "potential": out[7]}
 
     def debug(self, which, dtype, count):
         out = np.zeros(count, dtype=dtype)

@@ -39,6 +39,7 @@ struct nb_sim {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool have_bodies = false;
+    bool first_kick = true;  // leapfrog: the next step is the first since the bodies were set
 
     Units units{};
     ForceConsts fc{};
@@ -148,6 +149,7 @@ IntegrateArgs integrate_args(const nb_sim *s, int do_integrate)
     IntegrateArgs ia;
     ia.acc_factor = s->units.acc_factor;
     ia.dt = s->p.dt;
+    ia.dt_kick = (s->p.integrator == NB_INT_LEAPFROG && s->first_kick) ? 0.5 * s->p.dt : s->p.dt;
     ia.inv_len_unit = 1.0 / s->units.len_unit;
     ia.do_integrate = do_integrate;
     return ia;
@@ -211,6 +213,7 @@ int step_local(nb_sim *s, int do_integrate)
 
 int step_finish(nb_sim *s)
 {
+    s->first_kick = false;
     if (s->alg == NB_ALG_DIRECT) {
         // records of the bodies other ranks advanced come from the gathered positions
         if (s->world > 1) {
@@ -292,6 +295,10 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
     if (!(s->p.theta >= 0) || !(s->p.collision_th >= 0) || !(s->p.eps >= 0)) {
         delete s;
         return fail(NB_ERR_ARG, "nb_create: theta, collision_th and eps must be >= 0");
+    }
+    if (s->p.integrator != NB_INT_EULER && s->p.integrator != NB_INT_LEAPFROG) {
+        delete s;
+        return fail(NB_ERR_ARG, "nb_create: integrator must be NB_INT_EULER or NB_INT_LEAPFROG");
     }
     s->n = n;
     s->alg = alg;
@@ -402,6 +409,7 @@ int nb_set_bodies(nb_sim *s, const nb_body *b, int n)
     NB_HIP(hipStreamSynchronize(s->stream));
     s->have_bodies = true;
     s->mid_step = false;
+    s->first_kick = true;
     return NB_OK;
 }
 
@@ -491,6 +499,11 @@ int nb_read_bodies(nb_sim *s, nb_body *out)
     std::vector<double2> pos(n), vel(n), acc(n);
     std::vector<double> mass(n), radius(n);
     std::vector<uint8_t> dyn(n);
+    // leapfrog keeps velocities half a step behind the positions; bring them level with the
+    // force at the current positions
+    const bool half_step = s->p.integrator == NB_INT_LEAPFROG && !s->first_kick && !s->mid_step;
+    if (half_step)
+        NB_TRY(step_local(s, 0));
     NB_HIP(hipStreamSynchronize(s->stream));
     NB_HIP(hipMemcpy(pos.data(), s->pos, sizeof(double2) * n, hipMemcpyDeviceToHost));
     NB_HIP(hipMemcpy(vel.data(), s->vel, sizeof(double2) * n, hipMemcpyDeviceToHost));
@@ -507,7 +520,49 @@ int nb_read_bodies(nb_sim *s, nb_body *out)
         x.position = {pos[k].x, pos[k].y};
         x.velocity = {vel[k].x, vel[k].y};
         x.acceleration = {acc[k].x, acc[k].y};
+        if (half_step && k >= s->t0 && k < s->t1) {
+            x.velocity.x += 0.5 * s->p.dt * acc[k].x;
+            x.velocity.y += 0.5 * s->p.dt * acc[k].y;
+        }
     }
+    return NB_OK;
+}
+
+int nb_diagnostics(nb_sim *s, double *out, int count)
+{
+    if (!s || !out || count < 1)
+        return fail(NB_ERR_ARG, "nb_diagnostics: bad argument");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb_diagnostics: no bodies were set");
+    std::vector<nb_body> b(s->n);
+    NB_TRY(nb_read_bodies(s, b.data()));
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const nb_body &x : b) {
+        v[0] += x.mass;
+        v[1] += x.mass * x.position.x;
+        v[2] += x.mass * x.position.y;
+        v[3] += x.mass * x.velocity.x;
+        v[4] += x.mass * x.velocity.y;
+        v[5] += x.mass * (x.position.x * x.velocity.y - x.position.y * x.velocity.x);
+        v[6] += 0.5 * x.mass * (x.velocity.x * x.velocity.x + x.velocity.y * x.velocity.y);
+    }
+    if (v[0] != 0) {
+        v[1] /= v[0];
+        v[2] /= v[0];
+    }
+    v[7] = std::nan("");
+    if (count > 7 && s->n <= 131072) {
+        double *d = nullptr;
+        NB_TRY(dev_alloc(d, 1));
+        int rc = potential_energy(s->stream, s->pos, s->mass, s->radius, s->n, s->p.gravity, s->p.eps,
+                                  s->p.collision_th, d);
+        if (rc == NB_OK && hipStreamSynchronize(s->stream) == hipSuccess)
+            (void)hipMemcpy(&v[7], d, sizeof(double), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        NB_TRY(rc);
+    }
+    for (int k = 0; k < count && k < 8; ++k)
+        out[k] = v[k];
     return NB_OK;
 }
 

@@ -1005,8 +1005,8 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         const double2 aa = dynamic ? make_double2(ax, ay) : a.acc[body];
         double2 v = a.vel[body];
         double2 p = pd;
-        v.x += aa.x * a.ia.dt;
-        v.y += aa.y * a.ia.dt;
+        v.x += aa.x * a.ia.dt_kick;
+        v.y += aa.y * a.ia.dt_kick;
         p.x += v.x * a.ia.dt;
         p.y += v.y * a.ia.dt;
         a.vel[body] = v;

@@ -48,7 +48,8 @@ struct ForceConsts {
 
 struct IntegrateArgs {
     double acc_factor;
-    double dt;
+    double dt;       // drift: x += v dt
+    double dt_kick;  // kick: v += a dt_kick (dt, or dt/2 on the first leapfrog step)
     double inv_len_unit;
     int do_integrate;  // 0: only store accelerations
 };
@@ -72,5 +73,10 @@ size_t direct_meta_bytes(int n);
 // pos/mass/radius (double) -> posm records + scaled radius, bodies [i0, i1)
 int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int i0, int i1,
               double inv_len_unit, double inv_mass_unit, double collision_th, float4 *posm, float *rad);
+
+// ---- diagnostics (nb_diag.hip) ----
+// potential energy of the pairs outside the cutoff, FP64, O(n^2); *out is a device double
+int potential_energy(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int n, double gravity,
+                     double eps, double collision_th, double *out);
 
 }  // namespace nb

@@ -142,8 +142,8 @@ __device__ __forceinline__ void integrate_one(const DirectLaunch &a, int i, doub
     if (a.ia.do_integrate) {
         double2 v = a.vel[i];
         double2 p = a.pos_cur[i];
-        v.x += ax * a.ia.dt;
-        v.y += ay * a.ia.dt;
+        v.x += ax * a.ia.dt_kick;
+        v.y += ay * a.ia.dt_kick;
         p.x += v.x * a.ia.dt;
         p.y += v.y * a.ia.dt;
         a.vel[i] = v;

@@ -9,7 +9,8 @@
 // BarnesHut unless --alg direct is given.  Exactly three positional arguments, or none for
 // the defaults (N 300, Sim 0, Iter 300), as in the reference; bad values print the reference's
 // message and return -1.  Additive flags: --alg bh|direct, --seed S, --theta T, --dump FILE,
-// --dump-every K, --iters K (nBodyCPU form), --quiet.
+// --dump-every K, --iters K (nBodyCPU form), --integrator euler|leapfrog, --energy (prints the
+// conserved quantities before and after the run), --quiet.
 #include <chrono>
 #include <cstdint>
 #include <cstring>
@@ -73,7 +74,8 @@ int main(int argc, char **argv)
     double theta = -1;
     std::string dump;
     int dump_every = 1, iters_flag = 300;
-    bool quiet = false;
+    bool quiet = false, energy = false;
+    int integrator = NB_INT_EULER;
     std::vector<const char *> pos;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -97,6 +99,11 @@ int main(int argc, char **argv)
             dump_every = std::atoi(next("--dump-every"));
         else if (a == "--iters")
             iters_flag = std::atoi(next("--iters"));
+        else if (a == "--integrator") {
+            std::string v = next("--integrator");
+            integrator = v == "leapfrog" ? NB_INT_LEAPFROG : NB_INT_EULER;
+        } else if (a == "--energy")
+            energy = true;
         else if (a == "--quiet")
             quiet = true;
         else
@@ -129,6 +136,7 @@ int main(int argc, char **argv)
     nb_default_params(&params);
     if (theta >= 0)
         params.theta = theta;
+    params.integrator = integrator;
     if (dump_every < 1)
         dump_every = 1;
 
@@ -142,6 +150,14 @@ int main(int argc, char **argv)
             return EXIT_FAILURE;
         }
     }
+    auto print_energy = [&](const char *when) {
+        double d[8];
+        nb.diagnostics(d);
+        std::cout << when << ": E=" << d[6] + d[7] << " K=" << d[6] << " U=" << d[7] << " P=(" << d[3] << ", " << d[4]
+                  << ") L=" << d[5] << std::endl;
+    };
+    if (energy)
+        print_energy("start");
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < iters; ++i) {
         nb.update();
@@ -154,6 +170,8 @@ int main(int argc, char **argv)
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (f)
         std::fclose(f);
+    if (energy)
+        print_energy("end");
     if (!quiet)
         std::cout << (alg == NB_ALG_DIRECT ? "direct sum" : "Barnes-Hut") << " N=" << nBodies << " sim=" << sim
                   << " iters=" << iters << " : " << ms / iters << " ms/step" << std::endl;

@@ -43,6 +43,7 @@ public:
     void readDeviceBodies() { check(nb_read_bodies(sim_, bodies_.data()), "nb_read_bodies"); }
     nb_body *getBodies() { return bodies_.data(); }
     void sync() { check(nb_sync(sim_), "nb_sync"); }
+    void diagnostics(double out[8]) { check(nb_diagnostics(sim_, out, 8), "nb_diagnostics"); }
     int size() const { return n_; }
     nb_sim *handle() { return sim_; }
 

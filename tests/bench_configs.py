@@ -1,0 +1,48 @@
+"""Times the BASELINE.json configurations on one GPU (tuning/record aid, not a test)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import load_package  # noqa: E402
+
+nb = load_package()
+
+
+def run(alg, scenario, n, steps, warm=2):
+    t = time.perf_counter()
+    b = nb.init_scenario(scenario, n, 12345)
+    tgen = time.perf_counter() - t
+    with nb.NBodySim(n, alg) as sim:
+        t = time.perf_counter()
+        sim.set_bodies(b)
+        tset = time.perf_counter() - t
+        sim.update(warm)
+        sim.sync()
+        sim.set_stage_timing(True, counters=False)
+        t = time.perf_counter()
+        sim.update(steps)
+        sim.sync()
+        dt = (time.perf_counter() - t) / steps
+        st = sim.stage_ms()
+        t = time.perf_counter()
+        out = sim.read_bodies()
+        tread = time.perf_counter() - t
+    assert np.all(np.isfinite(out["pos"]))
+    name = {0: "direct", 1: "BH"}[alg] + " " + {0: "spiral", 1: "random", 2: "collision", 3: "solar"}[scenario]
+    extra = "%.0f Ginter/s" % (n * n / dt / 1e9) if alg == 0 else " ".join("%s=%.2f" % kv for kv in st.items() if kv[1] > 0)
+    print("%-20s N=%-9d %9.3f ms/step  %s  (gen %.1fs set %.1fs read %.2fs)" % (name, n, dt * 1e3, extra, tgen, tset, tread), flush=True)
+
+
+which = sys.argv[1:] or ["c2", "c3", "c4", "c5"]
+if "c2" in which:
+    run(nb.DIRECT, nb.SPIRAL, 65536, 20)
+if "c3" in which:
+    run(nb.BARNES_HUT, nb.SPIRAL, 1000000, 10)
+if "c4" in which:
+    run(nb.BARNES_HUT, nb.COLLISION, 5000000, 10)
+if "c5" in which:
+    run(nb.DIRECT, nb.SPIRAL, 1000000, 3, 1)
+    run(nb.BARNES_HUT, nb.SPIRAL, 50000000, 3, 1)

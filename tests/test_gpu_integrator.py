@@ -1,0 +1,140 @@
+"""Leapfrog (kick-drift-kick) option and the conserved-quantity diagnostics.
+
+The reference has one integrator (semi-implicit Euler, src/cpu/directSum.cpp:49-67) and no
+diagnostics, so nothing of the reference pins these: parity unpinned.  They are checked against
+a numpy restatement of kick-drift-kick that takes its accelerations from the oracle, and against
+numpy sums over the bodies the library returns.
+"""
+import numpy as np
+import pytest
+
+from conftest import bodies_from_golden, golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def kdk_reference(oracle, b, nsteps, accel):
+    """Positions and time-centred velocities after nsteps of kick-drift-kick, FP64."""
+    b = b.copy()
+    dt = oracle.params().dt
+    dyn = b["is_dynamic"] != 0
+    for _ in range(nsteps):
+        a = accel(b)
+        a[~dyn] = 0.0
+        b["vel"] += 0.5 * dt * a
+        b["pos"] += dt * b["vel"]
+        a = accel(b)
+        a[~dyn] = 0.0
+        b["vel"] += 0.5 * dt * a
+    b["acc"] = a
+    return b
+
+
+@pytest.mark.parametrize("alg", ["direct", "bh"])
+@pytest.mark.parametrize("name", ["spiral_n256", "random_n256", "solar_n5"])
+def test_leapfrog_matches_kdk(nb, oracle, alg, name):
+    b0 = bodies_from_golden(golden(name))
+    steps = 25
+    accel = (lambda b: oracle.direct_accel(b)) if alg == "direct" else (lambda b: oracle.bh_accel(b))
+    want = kdk_reference(oracle, b0, steps, accel)
+    sim = nb.NBodySim(len(b0), nb.DIRECT if alg == "direct" else nb.BARNES_HUT,
+                      nb.default_params(integrator=nb.LEAPFROG))
+    sim.set_bodies(b0)
+    sim.update(steps)
+    got = sim.read_bodies()
+    sim.close()
+    scale = np.abs(want["pos"]).max()
+    assert np.abs(got["pos"] - want["pos"]).max() / scale < 1e-6
+    vscale = np.abs(want["vel"]).max()
+    assert np.abs(got["vel"] - want["vel"]).max() / vscale < 1e-4  # FP32 forces accumulate in velocities
+    assert rel_err(got["acc"], want["acc"]).max() < (1e-5 if alg == "direct" else 1e-4)
+
+
+def test_leapfrog_read_does_not_disturb_the_run(nb):
+    b0 = bodies_from_golden(golden("spiral_n256"))
+    p = nb.default_params(integrator=nb.LEAPFROG)
+    a = nb.NBodySim(len(b0), nb.DIRECT, p)
+    a.set_bodies(b0)
+    a.update(10)
+    ra = a.read_bodies()
+    a.close()
+    c = nb.NBodySim(len(b0), nb.DIRECT, p)
+    c.set_bodies(b0)
+    for _ in range(10):
+        c.update(1)
+        rc = c.read_bodies()  # synchronises velocities on the host copy only
+    c.close()
+    assert np.array_equal(ra["pos"], rc["pos"]) and np.array_equal(ra["vel"], rc["vel"])
+
+
+def test_euler_is_the_default_and_unchanged(nb, oracle):
+    b0 = bodies_from_golden(golden("spiral_n256"))
+    assert nb.default_params().integrator == nb.EULER
+    sim = nb.NBodySim(len(b0), nb.DIRECT)
+    sim.set_bodies(b0)
+    sim.update(10)
+    got = sim.read_bodies()
+    sim.close()
+    want = oracle.direct_step(b0, 10)
+    assert np.abs(got["pos"] - want["pos"]).max() / np.abs(want["pos"]).max() < 1e-6
+
+
+def test_bad_integrator_is_rejected(nb):
+    with pytest.raises(nb.NBodyError):
+        nb.NBodySim(16, nb.DIRECT, nb.default_params(integrator=7))
+
+
+def numpy_diagnostics(b, p):
+    m = b["mass"]
+    x, v = b["pos"], b["vel"]
+    d = x[None, :, :] - x[:, None, :]
+    r = np.sqrt((d ** 2).sum(-1))
+    rs = b["radius"][:, None] + b["radius"][None, :] + p.collision_th
+    keep = ~(rs >= r)
+    iu = np.triu(np.ones_like(keep, dtype=bool), 1)
+    pot = -(p.gravity * m[:, None] * m[None, :] / np.sqrt(r ** 2 + p.eps ** 2))[keep & iu].sum()
+    return {"mass": m.sum(), "com": (m[:, None] * x).sum(0) / m.sum(), "momentum": (m[:, None] * v).sum(0),
+            "angular_momentum": (m * (x[:, 0] * v[:, 1] - x[:, 1] * v[:, 0])).sum(),
+            "kinetic": 0.5 * (m * (v ** 2).sum(1)).sum(), "potential": pot}
+
+
+@pytest.mark.parametrize("name", ["random_n256", "collision_n4096", "solar_n5"])
+def test_diagnostics_match_numpy(nb, name):
+    b0 = bodies_from_golden(golden(name))
+    sim = nb.NBodySim(len(b0), nb.BARNES_HUT)
+    sim.set_bodies(b0)
+    sim.update(3)
+    d = sim.diagnostics()
+    b = sim.read_bodies()
+    sim.close()
+    w = numpy_diagnostics(b, nb.default_params())
+    assert d["mass"] == pytest.approx(w["mass"], rel=1e-12)
+    assert np.allclose(d["com"], w["com"], rtol=1e-10, atol=1e-6 * np.abs(b["pos"]).max())
+    pscale = (b["mass"][:, None] * np.abs(b["vel"])).sum()
+    assert np.allclose(d["momentum"], w["momentum"], rtol=1e-10, atol=1e-12 * pscale)
+    assert d["angular_momentum"] == pytest.approx(w["angular_momentum"], rel=1e-9)
+    assert d["kinetic"] == pytest.approx(w["kinetic"], rel=1e-12)
+    assert d["potential"] == pytest.approx(w["potential"], rel=1e-10)
+
+
+def test_leapfrog_conserves_energy_better_than_euler(nb):
+    """Solar system, 2000 steps of dt = 25000 s: the time-centred energy of kick-drift-kick
+    oscillates at second order in dt, semi-implicit Euler's at first order."""
+    b0 = bodies_from_golden(golden("solar_n5"))
+    drift = {}
+    for integ in (nb.EULER, nb.LEAPFROG):
+        sim = nb.NBodySim(len(b0), nb.DIRECT, nb.default_params(integrator=integ))
+        sim.set_bodies(b0)
+        d = sim.diagnostics()
+        e0 = d["kinetic"] + d["potential"]
+        l0 = d["angular_momentum"]
+        worst = 0.0
+        for _ in range(20):
+            sim.update(100)
+            d = sim.diagnostics()
+            worst = max(worst, abs(d["kinetic"] + d["potential"] - e0) / abs(e0))
+        assert abs(d["angular_momentum"] - l0) / abs(l0) < 1e-5
+        drift[integ] = worst
+        sim.close()
+    assert drift[nb.LEAPFROG] < 0.2 * drift[nb.EULER]
+    assert drift[nb.LEAPFROG] < 1e-4
