@@ -120,6 +120,155 @@ __global__ void k_cmpsel(float *out, float b, float c)
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
 }
 
+
+// ---- issue costs of the instruction kinds the tree traversal is made of ----
+
+// 8 independent vector compares that write a scalar register pair
+__global__ void k_cmp_sgpr(float *out, float b, float c)
+{
+    float a0 = threadIdx.x;
+    unsigned long long acc = 0;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_cmp_gt_f32_e64 s[20:21], %1, %2\n\t"
+                     "v_cmp_gt_f32_e64 s[22:23], %1, %3\n\t"
+                     "v_cmp_gt_f32_e64 s[24:25], %2, %1\n\t"
+                     "v_cmp_gt_f32_e64 s[26:27], %3, %1\n\t"
+                     "v_cmp_gt_f32_e64 s[28:29], %1, %2\n\t"
+                     "v_cmp_gt_f32_e64 s[30:31], %1, %3\n\t"
+                     "v_cmp_gt_f32_e64 s[36:37], %2, %1\n\t"
+                     "v_cmp_gt_f32_e64 s[38:39], %3, %1\n\t"
+                     "s_mov_b64 %0, s[38:39]"
+                     : "=s"(acc)
+                     : "v"(a0), "v"(b), "v"(c)
+                     : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s36", "s37",
+                       "s38", "s39");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + (float)acc;
+}
+
+// 8 independent v_readfirstlane_b32
+__global__ void k_rfl(float *out, float b, float c)
+{
+    float a0 = threadIdx.x;
+    unsigned acc = 0;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_readfirstlane_b32 s20, %1\n\t"
+                     "v_readfirstlane_b32 s21, %2\n\t"
+                     "v_readfirstlane_b32 s22, %3\n\t"
+                     "v_readfirstlane_b32 s23, %1\n\t"
+                     "v_readfirstlane_b32 s24, %2\n\t"
+                     "v_readfirstlane_b32 s25, %3\n\t"
+                     "v_readfirstlane_b32 s26, %1\n\t"
+                     "v_readfirstlane_b32 s27, %2\n\t"
+                     "s_mov_b32 %0, s27"
+                     : "=s"(acc)
+                     : "v"(a0), "v"(b), "v"(c)
+                     : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + (float)acc;
+}
+
+// 8 independent scalar 64-bit logic operations
+__global__ void k_salu(float *out, float b, float c)
+{
+    unsigned long long acc = 0;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("s_and_b64 s[20:21], exec, exec\n\t"
+                     "s_or_b64 s[22:23], exec, exec\n\t"
+                     "s_and_b64 s[24:25], exec, exec\n\t"
+                     "s_or_b64 s[26:27], exec, exec\n\t"
+                     "s_and_b64 s[28:29], exec, exec\n\t"
+                     "s_or_b64 s[30:31], exec, exec\n\t"
+                     "s_and_b64 s[36:37], exec, exec\n\t"
+                     "s_or_b64 %0, exec, s[36:37]"
+                     : "=s"(acc)
+                     :
+                     : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s36", "s37",
+                       "scc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)acc + c;
+}
+
+// 4 v_fma_f32 and 4 scalar operations interleaved, all independent: do they share an issue slot?
+__global__ void k_valu_salu(float *out, float b, float c)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    unsigned long long acc = 0;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_fma_f32 %0, %0, %5, %6\n\t"
+                     "s_and_b64 s[20:21], exec, exec\n\t"
+                     "v_fma_f32 %1, %1, %5, %6\n\t"
+                     "s_or_b64 s[22:23], exec, exec\n\t"
+                     "v_fma_f32 %2, %2, %5, %6\n\t"
+                     "s_and_b64 s[24:25], exec, exec\n\t"
+                     "v_fma_f32 %3, %3, %5, %6\n\t"
+                     "s_or_b64 %4, exec, s[24:25]"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=s"(acc)
+                     : "v"(b), "v"(c)
+                     : "s20", "s21", "s22", "s23", "s24", "s25", "scc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (float)acc;
+}
+
+// a dependent chain crossing between the units, as one tree-node visit does:
+// compare -> scalar logic -> scalar compare -> branch (never taken) -> select, 2 per iteration
+__global__ void k_cross(float *out, float b, float c)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %2\n\t"
+                     "s_and_b64 s[20:21], s[20:21], exec\n\t"
+                     "s_cmp_eq_u64 s[20:21], 0\n\t"
+                     "s_cbranch_scc1 1f\n\t"
+                     "v_cndmask_b32_e64 %0, %3, %0, s[20:21]\n\t"
+                     "1:\n\t"
+                     "v_cmp_gt_f32_e64 s[22:23], %1, %2\n\t"
+                     "s_and_b64 s[22:23], s[22:23], exec\n\t"
+                     "s_cmp_eq_u64 s[22:23], 0\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "v_cndmask_b32_e64 %1, %3, %1, s[22:23]\n\t"
+                     "2:"
+                     : "+v"(a0), "+v"(a1)
+                     : "v"(b), "v"(c)
+                     : "s20", "s21", "s22", "s23", "scc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1;
+}
+
+// 8 taken branches per iteration
+__global__ void k_branch(float *out, float b, float c)
+{
+    float a0 = threadIdx.x;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("s_branch 1f\n\t s_nop 0\n\t 1: s_branch 2f\n\t s_nop 0\n\t 2: s_branch 3f\n\t s_nop 0\n\t 3: s_branch 4f\n\t"
+                     "s_nop 0\n\t 4: s_branch 5f\n\t s_nop 0\n\t 5: s_branch 6f\n\t s_nop 0\n\t 6: s_branch 7f\n\t s_nop 0\n\t"
+                     "7: s_branch 8f\n\t s_nop 0\n\t 8: v_add_f32 %0, %0, %1"
+                     : "+v"(a0)
+                     : "v"(b));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + c;
+}
+
+// 8 LDS broadcast reads of 16 B per iteration, each waited for (the visit loop's access)
+__global__ void k_ldsb(float *out, float b, float c)
+{
+    __shared__ float4 buf[256];
+    buf[threadIdx.x] = make_float4(b, c, b, c);
+    __syncthreads();
+    float acc = 0.f;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 v;
+            const unsigned addr = (unsigned)(size_t)&buf[(i + k) & 255];
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr));
+            acc += v.x;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 template <typename K>
 static double run(K kernel, int blocks, float *out, int reps)
 {
@@ -162,6 +311,19 @@ int main()
         double mix_rate = lanes * ITERS * 8 / t;
         t = run(k_cmpsel, blocks, out, reps);
         double sel_rate = lanes * ITERS * 8 / t;
+        {
+            const double simd_cycles = 1.0;  // per-SIMD instruction slots: time * clock / (ITERS * 8 * waves)
+            (void)simd_cycles;
+            struct { const char *name; double t; double per_iter; } rows[] = {
+                {"v_cmp->sgpr", run(k_cmp_sgpr, blocks, out, reps), 8}, {"v_readfirstlane", run(k_rfl, blocks, out, reps), 8},
+                {"salu b64", run(k_salu, blocks, out, reps), 8},        {"4 fma + 4 salu", run(k_valu_salu, blocks, out, reps), 8},
+                {"cross chain x2", run(k_cross, blocks, out, reps), 2}, {"taken branch", run(k_branch, blocks, out, reps), 8},
+                {"lds b128 bcast", run(k_ldsb, blocks, out, reps), 8},  {"v_fma", run(k_fma, blocks, out, reps), 8}};
+            printf("waves/SIMD %d, cycles per item per SIMD (at the nominal clock):", wps);
+            for (auto &r : rows)
+                printf("  %s %.2f", r.name, r.t * clk / (ITERS * r.per_iter * wps));
+            printf("\n");
+        }
         printf("waves/SIMD %d: fma %.2f Tlane-op/s (%.1f TFLOP/s, %.1f lane-op/clk/CU) | pk_fma %.2f Tfma/s (%.1f TFLOP/s) | "
                "rsq %.2f T/s | mix(2rsq+6fma) %.2f Tinst/s | cmp+cndmask %.2f Tinst/s\n",
                wps, fma_rate / 1e12, 2 * fma_rate / 1e12, fma_rate / clk / cus, pk_rate / 1e12, 2 * pk_rate / 1e12,

@@ -110,6 +110,7 @@ void choose_units(nb_sim *s, const nb_body *b, int n)
     // 2^-26 of that cannot change a float sum r^3 + eps3.
     const double c3 = (double)s->fc.cth * s->fc.cth * s->fc.cth;
     s->fc.exact_denom = !((double)s->fc.eps3 <= std::ldexp(c3, -26));
+    s->fc.eps2_negligible = (double)s->fc.eps2 <= std::ldexp((double)s->fc.cth * s->fc.cth, -26);
 }
 
 // Exchange order = bodies sorted by a 2 x 16-bit Morton code of their initial positions.

@@ -746,7 +746,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 // ------------------------------------------------------------------ 6 traversal + integration
 
 #ifndef NB_TR_STACK
-#define NB_TR_STACK 384
+#define NB_TR_STACK 236
 #endif
 constexpr int TR_STACK = NB_TR_STACK;     // entries per wave
 constexpr int TR_HIGH = TR_STACK - 100;   // above this the wave pops one node at a time: a
@@ -785,25 +785,24 @@ __device__ __forceinline__ float readlane_f(float v, int l)
 // 1e-6 of the distance; the band is several times that.
 constexpr float TR_BAND = 4.0e-5f;
 
-// The force of one accepted cell or body on the lane's target.
-template <bool EXACT>
-__device__ __forceinline__ void add_force(float dx, float dy, float d2, float nm, float eps2, float eps3, float &fx,
-                                          float &fy)
+// Scale of the force of one accepted cell or body on the lane's target, m / r^3 with
+// r^2 = d^2 + eps2.  FM_EXACT keeps the reference's second softening term in the denominator
+// (r^3 + eps3); FM_NOEPS leaves eps out altogether: the host selects it when eps2 is below the
+// float resolution of every distance that can contribute (all are beyond the cutoff).
+enum { FM_NOEPS = 0, FM_EPS = 1, FM_EXACT = 2 };
+template <int MODE>
+__device__ __forceinline__ float force_scale(float d2, float nm, float eps2, float eps3)
 {
-    const float r2 = d2 + eps2;
-    float s;
-    if (EXACT) {
+    if (MODE == FM_EXACT) {
+        const float r2 = d2 + eps2;
         const float r3 = r2 * __builtin_sqrtf(r2);
-        s = nm * __builtin_amdgcn_rcpf(r3 + eps3);
-    } else {
-        const float rinv = __builtin_amdgcn_rsqf(r2);
-        s = (nm * rinv) * (rinv * rinv);
+        return nm * __builtin_amdgcn_rcpf(r3 + eps3);
     }
-    fx = __builtin_fmaf(dx, s, fx);
-    fy = __builtin_fmaf(dy, s, fy);
+    const float rinv = __builtin_amdgcn_rsqf(MODE == FM_EPS ? d2 + eps2 : d2);
+    return (nm * rinv) * (rinv * rinv);
 }
 
-template <bool EXACT, bool STATS>
+template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
 {
     __shared__ uint32_t st_node[4][TR_STACK];
@@ -969,8 +968,10 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
 #endif
             if (okm != 0ull) {
                 asm volatile("" ::: "memory");  // keep the force arithmetic inside this branch
-                if (__builtin_amdgcn_inverse_ballot_w64(okm))
-                    add_force<EXACT>(dx, dy, d2, nm, eps2, eps3, fx, fy);
+                // lanes outside okm get a zero scale (their own may be inf or NaN: d2 can be 0)
+                const float sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? force_scale<MODE>(d2, nm, eps2, eps3) : 0.f;
+                fx = __builtin_fmaf(dx, sc, fx);
+                fy = __builtin_fmaf(dy, sc, fy);
             }
             if (STATS) {
                 n_eval += (unsigned long long)__popcll(mj);
@@ -1115,16 +1116,21 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     dim3 grid((waves + 3) / 4);
     if (ntarget <= 0)
         return NB_OK;
+    const int mode = a.fc.exact_denom ? FM_EXACT : (a.fc.eps2_negligible ? FM_NOEPS : FM_EPS);
     if (a.collect_stats) {
-        if (a.fc.exact_denom)
-            hipLaunchKernelGGL((k_bh_force<true, true>), grid, dim3(256), 0, s, f);
+        if (mode == FM_EXACT)
+            hipLaunchKernelGGL((k_bh_force<FM_EXACT, true>), grid, dim3(256), 0, s, f);
+        else if (mode == FM_EPS)
+            hipLaunchKernelGGL((k_bh_force<FM_EPS, true>), grid, dim3(256), 0, s, f);
         else
-            hipLaunchKernelGGL((k_bh_force<false, true>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh_force<FM_NOEPS, true>), grid, dim3(256), 0, s, f);
     } else {
-        if (a.fc.exact_denom)
-            hipLaunchKernelGGL((k_bh_force<true, false>), grid, dim3(256), 0, s, f);
+        if (mode == FM_EXACT)
+            hipLaunchKernelGGL((k_bh_force<FM_EXACT, false>), grid, dim3(256), 0, s, f);
+        else if (mode == FM_EPS)
+            hipLaunchKernelGGL((k_bh_force<FM_EPS, false>), grid, dim3(256), 0, s, f);
         else
-            hipLaunchKernelGGL((k_bh_force<false, false>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh_force<FM_NOEPS, false>), grid, dim3(256), 0, s, f);
     }
     hipLaunchKernelGGL(k_bh_finish_counters, dim3(1), dim3(64), 0, s, b.level_start, b.counters, b.levels_host);
     NB_HIP(hipGetLastError());

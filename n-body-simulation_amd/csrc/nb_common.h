@@ -44,6 +44,7 @@ struct ForceConsts {
     float eps3;      // eps^2 / len_unit^3 (the reference adds eps^2 to r^3)
     float cth;       // collision_th / len_unit
     int exact_denom; // 0: eps3 cannot change r^3 + eps3 in float for any pair outside the cutoff
+    int eps2_negligible;  // 1: eps2 cannot change d^2 + eps2 in float for any pair outside the cutoff
 };
 
 struct IntegrateArgs {

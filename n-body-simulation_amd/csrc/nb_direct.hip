@@ -40,6 +40,10 @@ namespace nb {
 #define NB_DS_DMA 1  // 1: stage tiles with global_load_lds (no staging registers), 0: through registers
 #endif
 
+#ifndef NB_DS_PACKED
+#define NB_DS_PACKED 1  // 1: cutoff-free runs on packed FP32 arithmetic
+#endif
+
 constexpr int DS_BLOCK = 256;
 constexpr int DS_TILE = 1024;  // records per LDS tile (16 KiB), two buffers
 constexpr int DS_SUB = 256;    // records per run with its own bounding box
@@ -262,6 +266,57 @@ __device__ __forceinline__ void run_pairs(const DirectLaunch &a, const float4 *r
     }
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// The cutoff-free loop on packed FP32 (v_pk_add/mul/fma_f32: two lanes of arithmetic per issue
+// slot): targets are taken two at a time, so every operation but the reciprocal square root
+// serves two pairs.  Same operations and rounding per pair as run_pairs<.., false, ..>.
+template <int TPT, bool UNIFORM>
+__device__ __forceinline__ void run_pairs_far(const DirectLaunch &a, const float4 *rec, float mu,
+                                              const float (&xi)[TPT], const float (&yi)[TPT], double (&sx)[TPT],
+                                              double (&sy)[TPT])
+{
+    static_assert(TPT % 2 == 0, "packed loop takes targets in pairs");
+    constexpr int P = TPT / 2;
+    const v2f eps2 = {a.fc.eps2, a.fc.eps2};
+    v2f x2[P], y2[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        x2[p] = v2f{xi[2 * p], xi[2 * p + 1]};
+        y2[p] = v2f{yi[2 * p], yi[2 * p + 1]};
+    }
+#pragma unroll 1
+    for (int c = 0; c < DS_SUB; c += DS_FLUSH) {
+        v2f fx[P], fy[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            fx[p] = fy[p] = v2f{0.f, 0.f};
+#pragma unroll NB_DS_UNROLL
+        for (int jj = 0; jj < DS_FLUSH; ++jj) {
+            const float4 b = rec[c + jj];
+            const v2f bx = {b.x, b.x}, by = {b.y, b.y}, bm = {b.z, b.z};
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const v2f dx = bx - x2[p];
+                const v2f dy = by - y2[p];
+                v2f r2 = __builtin_elementwise_fma(dx, dx, eps2);
+                r2 = __builtin_elementwise_fma(dy, dy, r2);
+                const v2f rinv = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                const v2f s = UNIFORM ? rinv * (rinv * rinv) : (bm * rinv) * (rinv * rinv);
+                fx[p] = __builtin_elementwise_fma(dx, s, fx[p]);
+                fy[p] = __builtin_elementwise_fma(dy, s, fy[p]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            sx[2 * p] += (double)(UNIFORM ? fx[p].x * mu : fx[p].x);
+            sx[2 * p + 1] += (double)(UNIFORM ? fx[p].y * mu : fx[p].y);
+            sy[2 * p] += (double)(UNIFORM ? fy[p].x * mu : fy[p].x);
+            sy[2 * p + 1] += (double)(UNIFORM ? fy[p].y * mu : fy[p].y);
+        }
+    }
+}
+
 __device__ __forceinline__ float uniform_f(float v)
 {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
@@ -377,7 +432,12 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
             const bool uni = m.mu == m.mu;
             const float4 *rec = cur + sub * DS_SUB;
             if (far) {
-                if (uni)
+                if (NB_DS_PACKED && !EXACT && TPT % 2 == 0) {
+                    if (uni)
+                        run_pairs_far<TPT, true>(a, rec, m.mu, xi, yi, sx, sy);
+                    else
+                        run_pairs_far<TPT, false>(a, rec, 0.f, xi, yi, sx, sy);
+                } else if (uni)
                     run_pairs<TPT, EXACT, false, true>(a, rec, j0, jend, m.mu, xi, yi, ri, ti, sx, sy);
                 else
                     run_pairs<TPT, EXACT, false, false>(a, rec, j0, jend, 0.f, xi, yi, ri, ti, sx, sy);

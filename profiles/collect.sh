@@ -7,6 +7,7 @@
 set -u
 R=${1:-r01}
 OUT=gpurun_out/prof_$R
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err || exit 1
