@@ -876,92 +876,78 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
             aux = a.node_aux[u];
         }
         top = base;
-        // Stage the batch in LDS: every lane then reads entry j with the same address (an LDS
-        // broadcast), which keeps the per-node data off the vector ALU's lane-read path.
-        batch[lane][0] = make_uint4(__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z),
-                                    __float_as_uint(rec.w));
-        batch[lane][1] = make_uint4((uint32_t)um, (uint32_t)(um >> 32), aux.x, aux.y);
+        // Stage the batch in LDS, cells first and bodies after them: every lane then reads entry
+        // j with the same address (an LDS broadcast), which keeps the per-node data off the
+        // vector ALU's lane-read path, and each kind of node gets a loop without the other's code.
+        const bool is_body = (__float_as_uint(rec.w) & 0x80000000u) != 0u;
+        const uint64_t cellm = __builtin_amdgcn_ballot_w64(lane < c && !is_body);
+        const uint64_t bodym = __builtin_amdgcn_ballot_w64(lane < c && is_body);
+        const int ncell = (int)__popcll(cellm);
+        const uint64_t mine = is_body ? bodym : cellm;
+        const int slot_j = (is_body ? ncell : 0) +
+                           (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+        if (lane < c) {
+            batch[slot_j][0] = make_uint4(__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z),
+                                          __float_as_uint(rec.w));
+            batch[slot_j][1] = make_uint4((uint32_t)um, (uint32_t)(um >> 32), aux.x, aux.y);
+        }
         __builtin_amdgcn_wave_barrier();
         float fx = 0.f, fy = 0.f;
+        // node index of batch entry j (only the rare FP64 re-decisions need it)
+        auto node_of = [&](int j) {
+            j = __builtin_amdgcn_readfirstlane(j);  // opaque: keeps a running copy of slot_j - j out of the loop
+            const uint64_t at = __builtin_amdgcn_ballot_w64(lane < c && slot_j == j);
+            return (uint32_t)__builtin_amdgcn_readlane((int)u, (int)__builtin_ctzll(at));
+        };
         // Per-lane conditions are kept as 64-bit lane masks in scalar registers (the result of a
-        // vector compare IS such a mask), so combining them costs scalar instructions only.  The
-        // one scalar unit of a CU serves all four SIMDs, so scalar instructions are the scarce
-        // resource of this loop: tests that are cheap in vector form are not branched around.
-        for (int j = 0; j < c; ++j) {
+        // vector compare IS such a mask), so combining them costs scalar instructions only.
+        // ---- cells: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
+        for (int j = 0; j < ncell; ++j) {
             const uint4 r = batch[j][0], q = batch[j][1];
             const float nx = __uint_as_float(r.x), ny = __uint_as_float(r.y), nm = __uint_as_float(r.z);
             const float nw = __uint_as_float(r.w);
-            const uint32_t nwbits = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w);
             const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
             const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
             const uint64_t mj = ((uint64_t)mhi << 32) | mlo;  // lanes this node is visited for
             const float dx = nx - xi, dy = ny - yi;
             const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-            uint64_t okm;
-            if (nwbits & 0x80000000u) {
-                // ---- a body: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
-                const float th = ri - nw;
-                const float t2 = th * th;
-                const float g = d2 - t2;
-                uint64_t passm = __builtin_amdgcn_ballot_w64(g >= 0.f);
+            const float g = d2 - nw;
+            uint64_t accm = __builtin_amdgcn_ballot_w64(g > 0.f);
 #ifdef NB_ABL_NOAMB
-                const uint64_t ambm = 0ull;
+            uint64_t ambm = 0ull;
 #else
-                const uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= t2 * TR_BAND) & mj;
+            uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= nw * TR_BAND);
 #endif
-                if (ambm != 0ull) {
-                    // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
-                    const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
-                    const double *nc = a.node_com + 4 * (size_t)uj;
-                    const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
-                    const double dist = sqrt(ex * ex + ey * ey);
-                    passm = __builtin_amdgcn_ballot_w64(!(rd + (-nc[3]) + a.collision_th > dist));
-                    if (STATS)
-                        n_recheck += 1;
-                }
-                okm = mj & passm;
-                if (self_test)  // the body itself has d2 == 0 (the reference skips it by pointer)
-                    okm &= __builtin_amdgcn_ballot_w64(d2 > 0.f);
-            } else {
-                // ---- a cell: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
-                const float g = d2 - nw;
-                uint64_t accm = __builtin_amdgcn_ballot_w64(g > 0.f);
-#ifdef NB_ABL_NOAMB
-                uint64_t ambm = 0ull;
-#else
-                uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= nw * TR_BAND);
-#endif
-                // outside 2 r_i + th of the centre of mass (barnesHut.cpp:75)
-                const float g2 = d2 - thn2;
-                uint64_t farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
+            // outside 2 r_i + th of the centre of mass (barnesHut.cpp:75)
+            const float g2 = d2 - thn2;
+            uint64_t farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
 #ifndef NB_ABL_NOAMB
-                ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band) & accm;
+            ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band) & accm;
 #endif
-                if ((ambm & mj) != 0ull) {
-                    const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
-                    const double *nc = a.node_com + 4 * (size_t)uj;
-                    const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
-                    const double dist = sqrt(ex * ex + ey * ey);
-                    accm = __builtin_amdgcn_ballot_w64(nc[3] / dist < a.theta);
-                    farm = __builtin_amdgcn_ballot_w64(!(rd * 2 + a.collision_th > dist));
-                    if (STATS)
-                        n_recheck += 1;
+            if ((ambm & mj) != 0ull) {
+                // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
+                const double *nc = a.node_com + 4 * (size_t)node_of(j);
+                const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
+                const double dist = sqrt(ex * ex + ey * ey);
+                accm = __builtin_amdgcn_ballot_w64(nc[3] / dist < a.theta);
+                farm = __builtin_amdgcn_ballot_w64(!(rd * 2 + a.collision_th > dist));
+                if (STATS)
+                    n_recheck += 1;
+            }
+            uint64_t okm = mj & accm & farm;
+            // Nothing below a cell that lies wholly inside the cutoff distance can contribute:
+            // every body and every centre of mass in it is closer than collision_th.  A lane
+            // that sees the cell that way does not open it.
+            const float prune = __uint_as_float(q.w);
+            const uint64_t om = mj & ~accm & ~__builtin_amdgcn_ballot_w64(d2 < prune);
+            if (om != 0ull) {
+                const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
+                const int cf = (int)(packed >> 3), nc = (int)(packed & 7u);
+                if (lane < nc) {
+                    snode[top + lane] = (uint32_t)(cf + lane);
+                    smask[top + lane] = om;
                 }
-                okm = mj & accm & farm;
-                // Nothing below a cell that lies wholly inside the cutoff distance can contribute:
-                // every body and every centre of mass in it is closer than collision_th.  A lane
-                // that sees the cell that way does not open it.
-                const float prune = __uint_as_float(q.w);
-                const uint64_t om = mj & ~accm & ~__builtin_amdgcn_ballot_w64(d2 < prune);
-                if (om != 0ull) {
-                    const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
-                    const int cf = (int)(packed >> 3), nc = (int)(packed & 7u);
-                    if (lane < nc) {
-                        snode[top + lane] = (uint32_t)(cf + lane);
-                        smask[top + lane] = om;
-                    }
-                    top += nc;
-                }
+                top += nc;
             }
 #ifdef NB_ABL_NOFORCE
             okm = 0ull;
@@ -969,6 +955,50 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
             if (okm != 0ull) {
                 asm volatile("" ::: "memory");  // keep the force arithmetic inside this branch
                 // lanes outside okm get a zero scale (their own may be inf or NaN: d2 can be 0)
+                const float sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? force_scale<MODE>(d2, nm, eps2, eps3) : 0.f;
+                fx = __builtin_fmaf(dx, sc, fx);
+                fy = __builtin_fmaf(dy, sc, fy);
+            }
+            if (STATS) {
+                n_eval += (unsigned long long)__popcll(mj);
+                n_acc += (unsigned long long)__popcll(okm);
+                n_visit += 1;
+            }
+        }
+        // ---- bodies: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
+        for (int j = ncell; j < c; ++j) {
+            const uint4 r = batch[j][0];
+            const uint2 q = *(const uint2 *)&batch[j][1];
+            const float nx = __uint_as_float(r.x), ny = __uint_as_float(r.y), nm = __uint_as_float(r.z);
+            const float nw = __uint_as_float(r.w);
+            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
+            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
+            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
+            const float dx = nx - xi, dy = ny - yi;
+            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+            const float th = ri - nw;
+            const float t2 = th * th;
+            const float g = d2 - t2;
+            uint64_t passm = __builtin_amdgcn_ballot_w64(g >= 0.f);
+#ifndef NB_ABL_NOAMB
+            const uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= t2 * TR_BAND) & mj;
+            if (ambm != 0ull) {
+                const double *nc = a.node_com + 4 * (size_t)node_of(j);
+                const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
+                const double dist = sqrt(ex * ex + ey * ey);
+                passm = __builtin_amdgcn_ballot_w64(!(rd + (-nc[3]) + a.collision_th > dist));
+                if (STATS)
+                    n_recheck += 1;
+            }
+#endif
+            uint64_t okm = mj & passm;
+            if (self_test)  // the body itself has d2 == 0 (the reference skips it by pointer)
+                okm &= __builtin_amdgcn_ballot_w64(d2 > 0.f);
+#ifdef NB_ABL_NOFORCE
+            okm = 0ull;
+#endif
+            if (okm != 0ull) {
+                asm volatile("" ::: "memory");
                 const float sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? force_scale<MODE>(d2, nm, eps2, eps3) : 0.f;
                 fx = __builtin_fmaf(dx, sc, fx);
                 fy = __builtin_fmaf(dy, sc, fy);
