@@ -799,7 +799,7 @@ __device__ __forceinline__ float force_scale(float d2, float nm, float eps2, flo
         return nm * __builtin_amdgcn_rcpf(r3 + eps3);
     }
     const float rinv = __builtin_amdgcn_rsqf(MODE == FM_EPS ? d2 + eps2 : d2);
-    return (nm * rinv) * (rinv * rinv);
+    return ((rinv * rinv) * rinv) * nm;  // one dependent chain: as two products the compiler packs them, at a loss
 }
 
 template <int MODE, bool STATS>
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
             const float g2 = d2 - thn2;
             uint64_t farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
 #ifndef NB_ABL_NOAMB
-            ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band) & accm;
+            ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band);
 #endif
             if ((ambm & mj) != 0ull) {
                 // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
