@@ -269,6 +269,48 @@ __global__ void k_ldsb(float *out, float b, float c)
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// 8 LDS broadcast reads per iteration issued back to back, one wait: throughput by access width
+template <int WIDTH>
+__global__ void k_ldsw(float *out, float b, float c)
+{
+    __shared__ float4 buf[256];
+    buf[threadIdx.x] = make_float4(b, c, b, c);
+    __syncthreads();
+    float acc = 0.f;
+    const unsigned base = (unsigned)(size_t)&buf[0];
+    for (int i = 0; i < ITERS; ++i) {
+        const unsigned addr = base + ((i & 15) << 7);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        if (WIDTH == 16) {
+            f4 v0, v1, v2, v3, v4, v5, v6, v7;
+            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+                         "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                         "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7)
+                         : "v"(addr));
+            acc += v0.x + v1.x + v2.x + v3.x + v4.x + v5.x + v6.x + v7.x;
+        } else if (WIDTH == 8) {
+            f2 v0, v1, v2, v3, v4, v5, v6, v7;
+            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:16\n\tds_read_b64 %2, %8 offset:32\n\t"
+                         "ds_read_b64 %3, %8 offset:48\n\tds_read_b64 %4, %8 offset:64\n\tds_read_b64 %5, %8 offset:80\n\t"
+                         "ds_read_b64 %6, %8 offset:96\n\tds_read_b64 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7)
+                         : "v"(addr));
+            acc += v0.x + v1.x + v2.x + v3.x + v4.x + v5.x + v6.x + v7.x;
+        } else {
+            float v0, v1, v2, v3, v4, v5, v6, v7;
+            asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:16\n\tds_read_b32 %2, %8 offset:32\n\t"
+                         "ds_read_b32 %3, %8 offset:48\n\tds_read_b32 %4, %8 offset:64\n\tds_read_b32 %5, %8 offset:80\n\t"
+                         "ds_read_b32 %6, %8 offset:96\n\tds_read_b32 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7)
+                         : "v"(addr));
+            acc += v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 template <typename K>
 static double run(K kernel, int blocks, float *out, int reps)
 {
@@ -318,7 +360,9 @@ int main()
                 {"v_cmp->sgpr", run(k_cmp_sgpr, blocks, out, reps), 8}, {"v_readfirstlane", run(k_rfl, blocks, out, reps), 8},
                 {"salu b64", run(k_salu, blocks, out, reps), 8},        {"4 fma + 4 salu", run(k_valu_salu, blocks, out, reps), 8},
                 {"cross chain x2", run(k_cross, blocks, out, reps), 2}, {"taken branch", run(k_branch, blocks, out, reps), 8},
-                {"lds b128 bcast", run(k_ldsb, blocks, out, reps), 8},  {"v_fma", run(k_fma, blocks, out, reps), 8}};
+                {"lds b128 bcast", run(k_ldsb, blocks, out, reps), 8},  {"v_fma", run(k_fma, blocks, out, reps), 8},
+                {"lds b128 x8", run(k_ldsw<16>, blocks, out, reps), 8}, {"lds b64 x8", run(k_ldsw<8>, blocks, out, reps), 8},
+                {"lds b32 x8", run(k_ldsw<4>, blocks, out, reps), 8}};
             printf("waves/SIMD %d, cycles per item per SIMD (at the nominal clock):", wps);
             for (auto &r : rows)
                 printf("  %s %.2f", r.name, r.t * clk / (ITERS * r.per_iter * wps));

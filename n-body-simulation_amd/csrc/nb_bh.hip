@@ -19,6 +19,8 @@
 //              every lane applies its OWN opening test (barnesHut.cpp:70-71), so each body
 //              accepts exactly the cells the reference accepts for it.  Integration
 //              (barnesHut.cpp:108-123) is fused into the epilogue.
+#include <type_traits>
+
 #include "nb_bh.h"
 
 namespace nb {
@@ -746,8 +748,12 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 // ------------------------------------------------------------------ 6 traversal + integration
 
 #ifndef NB_TR_STACK
-#define NB_TR_STACK 236
+#define NB_TR_STACK 278
 #endif
+#ifndef NB_TR_BATCH
+#define NB_TR_BATCH 48
+#endif
+constexpr int TR_BATCH = NB_TR_BATCH;     // nodes popped and visited together (at most one per lane)
 constexpr int TR_STACK = NB_TR_STACK;     // entries per wave
 constexpr int TR_HIGH = TR_STACK - 100;   // above this the wave pops one node at a time: a
                                           // depth-first descent adds at most 3 entries per tree
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     __shared__ uint32_t st_node[4][TR_STACK];
     __shared__ uint64_t st_mask[4][TR_STACK];
     // the batch being visited: per entry {record} and {lane mask, child word, prune threshold}
-    __shared__ __attribute__((aligned(16))) uint4 st_batch[4][64][2];
+    __shared__ __attribute__((aligned(16))) uint4 st_batch[4][TR_BATCH][2];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     uint32_t *snode = st_node[w];
     uint64_t *smask = st_mask[w];
@@ -834,6 +840,20 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
     const double2 pd = a.pos[body];
     const double rd = a.radius[body];
+    // Bounding box of the wave's targets and their largest cell cutoff: a cell whose centre of
+    // mass is farther from the box than that (with a margin far above float rounding) passes
+    // the cutoff test for every lane and cannot be pruned.  A batch made of such cells only is
+    // visited by a loop without those tests.
+    float gx0 = xi, gx1 = xi, gy0 = yi, gy1 = yi, safe2 = thn2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        gx0 = fminf(gx0, __shfl_xor(gx0, o));
+        gx1 = fmaxf(gx1, __shfl_xor(gx1, o));
+        gy0 = fminf(gy0, __shfl_xor(gy0, o));
+        gy1 = fmaxf(gy1, __shfl_xor(gy1, o));
+        safe2 = fmaxf(safe2, __shfl_xor(safe2, o));
+    }
+    safe2 *= 1.001f;
 
     double sx = 0.0, sy = 0.0;
     unsigned long long n_eval = 0, n_acc = 0, n_recheck = 0, n_visit = 0, n_batch = 0;
@@ -855,7 +875,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
             n_batch += 1;
             max_top = top > max_top ? top : max_top;
         }
-        int c = top < 64 ? top : 64;
+        int c = top < TR_BATCH ? top : TR_BATCH;
         int room = (TR_HIGH - top) / 3;
         if (room < 1)
             room = 1;
@@ -883,6 +903,8 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         const uint64_t cellm = __builtin_amdgcn_ballot_w64(lane < c && !is_body);
         const uint64_t bodym = __builtin_amdgcn_ballot_w64(lane < c && is_body);
         const int ncell = (int)__popcll(cellm);
+        const float ex = fmaxf(fmaxf(gx0 - rec.x, rec.x - gx1), 0.f), ey = fmaxf(fmaxf(gy0 - rec.y, rec.y - gy1), 0.f);
+        const bool all_far = (cellm & ~__builtin_amdgcn_ballot_w64(__builtin_fmaf(ex, ex, ey * ey) > safe2)) == 0ull;
         const uint64_t mine = is_body ? bodym : cellm;
         const int slot_j = (is_body ? ncell : 0) +
                            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
@@ -902,7 +924,8 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         // Per-lane conditions are kept as 64-bit lane masks in scalar registers (the result of a
         // vector compare IS such a mask), so combining them costs scalar instructions only.
         // ---- cells: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
-        for (int j = 0; j < ncell; ++j) {
+        auto visit_cell = [&](const int j, auto far_tag) {
+            constexpr bool FAR = decltype(far_tag)::value;
             const uint4 r = batch[j][0], q = batch[j][1];
             const float nx = __uint_as_float(r.x), ny = __uint_as_float(r.y), nm = __uint_as_float(r.z);
             const float nw = __uint_as_float(r.w);
@@ -918,28 +941,34 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
 #else
             uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= nw * TR_BAND);
 #endif
-            // outside 2 r_i + th of the centre of mass (barnesHut.cpp:75)
-            const float g2 = d2 - thn2;
-            uint64_t farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
+            // an accepted cell counts only outside 2 r_i + th of its centre of mass (barnesHut.cpp:75)
+            uint64_t farm = ~0ull;
+            if (!FAR) {
+                const float g2 = d2 - thn2;
+                farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
 #ifndef NB_ABL_NOAMB
-            ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band);
+                ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band);
 #endif
+            }
             if ((ambm & mj) != 0ull) {
                 // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
                 const double *nc = a.node_com + 4 * (size_t)node_of(j);
                 const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
                 const double dist = sqrt(ex * ex + ey * ey);
                 accm = __builtin_amdgcn_ballot_w64(nc[3] / dist < a.theta);
-                farm = __builtin_amdgcn_ballot_w64(!(rd * 2 + a.collision_th > dist));
+                if (!FAR)
+                    farm = __builtin_amdgcn_ballot_w64(!(rd * 2 + a.collision_th > dist));
                 if (STATS)
                     n_recheck += 1;
             }
-            uint64_t okm = mj & accm & farm;
+            const uint64_t macc = mj & accm;
+            uint64_t okm = FAR ? macc : macc & farm;
             // Nothing below a cell that lies wholly inside the cutoff distance can contribute:
             // every body and every centre of mass in it is closer than collision_th.  A lane
             // that sees the cell that way does not open it.
-            const float prune = __uint_as_float(q.w);
-            const uint64_t om = mj & ~accm & ~__builtin_amdgcn_ballot_w64(d2 < prune);
+            uint64_t om = mj ^ macc;
+            if (!FAR)
+                om &= ~__builtin_amdgcn_ballot_w64(d2 < __uint_as_float(q.w));
             if (om != 0ull) {
                 const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
                 const int cf = (int)(packed >> 3), nc = (int)(packed & 7u);
@@ -964,6 +993,13 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                 n_acc += (unsigned long long)__popcll(okm);
                 n_visit += 1;
             }
+        };
+        if (all_far) {
+            for (int j = 0; j < ncell; ++j)
+                visit_cell(j, std::true_type{});
+        } else {
+            for (int j = 0; j < ncell; ++j)
+                visit_cell(j, std::false_type{});
         }
         // ---- bodies: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
         for (int j = ncell; j < c; ++j) {
