@@ -401,15 +401,22 @@ __global__ void k_build_init(uint4 *node_meta, uint32_t *level_start, int n, uns
         counters[t] = 0ull;
 }
 
-// Slots of tree level d are dealt to the BH_SCAN_BLOCKS blocks in contiguous chunks that are
-// multiples of 256, the same way in the count and in the emit kernel.
+// Lanes that search one node's quadrant boundaries together.  The searches of a level with few
+// nodes are pure latency (a chain of dependent loads per node, over ranges of millions of
+// bodies near the root), so such levels give each node a whole wave or 8 lanes, which probe
+// 64 or 8 positions per round instead of one.
+__device__ __forceinline__ int search_group(uint32_t m) { return m <= 4096u ? 64 : (m <= 65536u ? 8 : 1); }
+
+// Slots of tree level d are dealt to the BH_SCAN_BLOCKS blocks in contiguous chunks (multiples
+// of 256 where a thread has a node to itself), the same way in the count and in the emit kernel.
 __device__ __forceinline__ void level_chunk(const uint32_t *level_start, int d, uint32_t &lbeg, uint32_t &m,
                                             uint32_t &cbeg, uint32_t &cend)
 {
     lbeg = level_start[d];
     m = level_start[d + 1] - lbeg;
     uint32_t chunk = (m + BH_SCAN_BLOCKS - 1) / BH_SCAN_BLOCKS;
-    chunk = (chunk + 255u) & ~255u;
+    if (search_group(m) == 1)
+        chunk = (chunk + 255u) & ~255u;
     cbeg = blockIdx.x * chunk;
     cend = cbeg + chunk;
     if (cbeg > m)
@@ -454,8 +461,47 @@ __device__ __forceinline__ void digit_boundaries(const uint64_t *keys, uint32_t 
     s3 = lo3;
 }
 
+// The same boundaries found by G lanes together (G = 8 or 64, a power of two; the G lanes are
+// consecutive lanes of one wave and all call this with the same range): every round each lane
+// probes one of G evenly spaced positions of each of the three ranges, and the first lane whose
+// digit reaches the boundary's value narrows that range to the gap before its probe.
+template <int G>
+__device__ __forceinline__ void digit_boundaries_group(const uint64_t *keys, uint32_t first, uint32_t end, int shift,
+                                                       uint32_t &s1, uint32_t &s2, uint32_t &s3)
+{
+    const int lane = threadIdx.x & 63, g = lane & (G - 1), gshift = lane & ~(G - 1);
+    const uint64_t gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+    uint32_t lo[3] = {first, first, first}, hi[3] = {end, end, end};
+    while (lo[0] < hi[0] || lo[1] < hi[1] || lo[2] < hi[2]) {
+        uint32_t probe[3];
+        bool reach[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const uint32_t len = hi[b] - lo[b];
+            probe[b] = lo[b] + (uint32_t)(((uint64_t)len * (uint32_t)(g + 1)) / (uint32_t)(G + 1));
+            reach[b] = len > 0u && ((uint32_t)(keys[len > 0u ? probe[b] : first] >> shift) & 3u) >= (uint32_t)(b + 1);
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const uint32_t len = hi[b] - lo[b];
+            if (len == 0u)
+                continue;
+            const uint64_t hit = (__builtin_amdgcn_ballot_w64(reach[b]) >> gshift) & gmask;
+            const int t = hit ? __builtin_ctzll(hit) : G;  // first probe at or past the boundary
+            const uint32_t before = t == 0 ? lo[b] : lo[b] + (uint32_t)(((uint64_t)len * (uint32_t)t) / (uint32_t)(G + 1)) + 1u;
+            const uint32_t at = t == G ? hi[b] : lo[b] + (uint32_t)(((uint64_t)len * (uint32_t)(t + 1)) / (uint32_t)(G + 1));
+            lo[b] = before;
+            hi[b] = at;
+        }
+    }
+    s1 = lo[0];
+    s2 = lo[1];
+    s3 = lo[2];
+}
+
 // What a node becomes: its quadrant boundaries and child count | cell level << 8 (0 children for
-// a leaf: one body, or several bodies with one key).
+// a leaf: one body, or several bodies with one key).  G lanes call it together for one node.
+template <int G>
 __device__ __forceinline__ uint4 classify_node(const uint64_t *keys, uint4 meta)
 {
     const uint32_t first = meta.x, count = meta.y, last = first + count - 1;
@@ -467,7 +513,10 @@ __device__ __forceinline__ uint4 classify_node(const uint64_t *keys, uint4 meta)
     const int shift = KEY_BITS - 2 - 2 * lvl;
     const uint32_t end = first + count;
     uint32_t s1, s2, s3;
-    digit_boundaries(keys, first, end, shift, s1, s2, s3);
+    if (G == 1)
+        digit_boundaries(keys, first, end, shift, s1, s2, s3);
+    else
+        digit_boundaries_group<G>(keys, first, end, shift, s1, s2, s3);
     const uint32_t nchild = (s1 > first) + (s2 > s1) + (s3 > s2) + (end > s3);
     return make_uint4(s1, s2, s3, nchild | ((uint32_t)lvl << 8));
 }
@@ -500,10 +549,33 @@ __global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4
     uint32_t lbeg, m, cbeg, cend;
     level_chunk(level_start, d, lbeg, m, cbeg, cend);
     int local = 0;
-    for (uint32_t slot = cbeg + threadIdx.x; slot < cend; slot += 256) {
-        const uint4 sp = classify_node(keys, node_meta[lbeg + slot]);
-        local += (int)(sp.w & 0xffu);
-        split[slot] = sp;
+    const int group = search_group(m);  // uniform over the grid
+    if (group == 64) {
+        for (uint32_t slot = cbeg + (threadIdx.x >> 6); slot < cend; slot += 4) {
+            const uint4 sp = classify_node<64>(keys, node_meta[lbeg + slot]);
+            if ((threadIdx.x & 63) == 0) {
+                local += (int)(sp.w & 0xffu);
+                split[slot] = sp;
+            }
+        }
+    } else if (group == 8) {
+        // a wave's eight groups stay together until the last of them is done (they share ballots)
+        for (uint32_t base = cbeg; base < cend; base += 32) {
+            const uint32_t slot = base + (threadIdx.x >> 3);
+            uint4 sp = make_uint4(0u, 0u, 0u, 0u);
+            if (slot < cend)
+                sp = classify_node<8>(keys, node_meta[lbeg + slot]);
+            if (slot < cend && (threadIdx.x & 7) == 0) {
+                local += (int)(sp.w & 0xffu);
+                split[slot] = sp;
+            }
+        }
+    } else {
+        for (uint32_t slot = cbeg + threadIdx.x; slot < cend; slot += 256) {
+            const uint4 sp = classify_node<1>(keys, node_meta[lbeg + slot]);
+            local += (int)(sp.w & 0xffu);
+            split[slot] = sp;
+        }
     }
     const int tot = block_sum_256(local);
     if (threadIdx.x == 0)
@@ -560,7 +632,7 @@ __global__ __launch_bounds__(256) void k_build_tail(const uint64_t *keys, uint4 
             const uint32_t slot = tile + threadIdx.x;
             uint4 sp = make_uint4(0u, 0u, 0u, 0u);
             if (slot < m)
-                sp = classify_node(keys, node_meta[lbeg + slot]);
+                sp = classify_node<1>(keys, node_meta[lbeg + slot]);
             int tile_total;
             const int excl = block_excl_scan_256((int)(sp.w & 0xffu), tile_total);
             if (slot < m)
