@@ -291,6 +291,9 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
 {
     __shared__ uint32_t wcnt[4][SORT_BINS];
     __shared__ uint32_t dbase[SORT_BINS];
+    __shared__ uint32_t lstart[SORT_BINS];
+    __shared__ uint64_t lkey[SORT_TILE];
+    __shared__ uint32_t lval[SORT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -330,7 +333,8 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
     }
     __syncthreads();
     {
-        // thread = digit: exclusive prefix over the four waves, plus this block's global base
+        // thread = digit: exclusive prefix over the four waves, the digit's place in the block's
+        // own sorted order, and where the block's run of that digit starts in the output
         uint32_t run = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -338,21 +342,35 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
             wcnt[k][tid] = run;
             run += c;
         }
-        // start of digit `tid` in the output = keys with a smaller digit (scan of the 256 totals)
         int all;
+        const int local_start = block_excl_scan_256((int)run, all);
+        // start of digit `tid` in the output = keys with a smaller digit (scan of the 256 totals)
         const int before = block_excl_scan_256((int)totals[tid], all);
-        dbase[tid] = (uint32_t)before + hist[(size_t)tid * nblk + blockIdx.x];
+        lstart[tid] = (uint32_t)local_start;
+        dbase[tid] = (uint32_t)before + hist[(size_t)tid * nblk + blockIdx.x] - (uint32_t)local_start;
     }
     __syncthreads();
+    // Keys go through LDS in the block's sorted order, so that consecutive threads write
+    // consecutive output positions of a digit's run instead of 64 separate places per wave.
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const int i = chunk + it * 64 + lane;
         if (i < n) {
             const uint32_t d = (uint32_t)(key[it] >> shift) & (SORT_BINS - 1);
-            const uint32_t dst = dbase[d] + wcnt[w][d] + rank[it];
-            keys_out[dst] = key[it];
-            idx_out[dst] = val[it];
+            const uint32_t p = lstart[d] + wcnt[w][d] + rank[it];
+            lkey[p] = key[it];
+            lval[p] = val[it];
         }
+    }
+    __syncthreads();
+    const int first = blockIdx.x * SORT_TILE;
+    const int count = n - first < SORT_TILE ? n - first : SORT_TILE;
+    for (int t = tid; t < count; t += 256) {
+        const uint64_t k = lkey[t];
+        const uint32_t d = (uint32_t)(k >> shift) & (SORT_BINS - 1);
+        const uint32_t dst = dbase[d] + (uint32_t)t;
+        keys_out[dst] = k;
+        idx_out[dst] = lval[t];
     }
 }
 
@@ -654,7 +672,7 @@ __global__ __launch_bounds__(256) void k_build_tail(const uint64_t *keys, uint4 
 static int launched_levels(const BhBuffers &b)
 {
     const uint32_t seen = b.levels_host ? *(volatile uint32_t *)b.levels_host : 0u;
-    int l = seen == 0u ? BH_MAX_DEPTH - 2 : (int)seen + 2;
+    int l = seen == 0u ? BH_MAX_DEPTH - 2 : (int)seen + 1;
     if (l > BH_MAX_DEPTH - 2)
         l = BH_MAX_DEPTH - 2;
     return l;
@@ -741,13 +759,12 @@ __device__ __forceinline__ void com_level(const ComArgs &a, int d)
             const uint32_t cf = meta.z;
             double sx = 0.0, sy = 0.0;
             mtot = 0.0;
+            const double2 *cc = (const double2 *)a.node_com;  // per node {x, y}, {mass, width}
             for (uint32_t c = cf; c < cf + nchild; ++c) {
-                const double ccx = a.node_com[4 * (size_t)c + 0];
-                const double ccy = a.node_com[4 * (size_t)c + 1];
-                const double cm = a.node_com[4 * (size_t)c + 2];
-                mtot += cm;
-                sx += ccx * cm;
-                sy += ccy * cm;
+                const double2 cxy = cc[2 * (size_t)c], cmw = cc[2 * (size_t)c + 1];
+                mtot += cmw.x;
+                sx += cxy.x * cmw.x;
+                sy += cxy.y * cmw.x;
             }
             cx = sx / mtot;
             cy = sy / mtot;
@@ -763,11 +780,9 @@ __device__ __forceinline__ void com_level(const ComArgs &a, int d)
             const double reach = a.cth * (1.0 - 1.0e-4) - sqrt(width * width + height * height);
             prune = reach > 0.0 ? (float)((reach * a.inv_len) * (reach * a.inv_len)) : -1.f;
         }
-        double *o = a.node_com + 4 * (size_t)u;
-        o[0] = cx;
-        o[1] = cy;
-        o[2] = mtot;
-        o[3] = width;
+        double2 *o = (double2 *)a.node_com + 2 * (size_t)u;
+        o[0] = make_double2(cx, cy);
+        o[1] = make_double2(mtot, width);
         a.node_rec[u] = rec;
         a.node_aux[u] = make_uint2((meta.z << 3) | nchild, __float_as_uint(prune));
     }
