@@ -205,7 +205,10 @@ int bh_keys(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // ------------------------------------------------------------------ 3 radix sort
 
-constexpr int SORT_ITEMS = 8;
+#ifndef NB_SORT_ITEMS
+#define NB_SORT_ITEMS 8
+#endif
+constexpr int SORT_ITEMS = NB_SORT_ITEMS;
 constexpr int SORT_TILE = 256 * SORT_ITEMS;
 constexpr int SORT_BITS = 8;
 constexpr int SORT_BINS = 1 << SORT_BITS;
@@ -983,19 +986,69 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
             aux = a.node_aux[u];
         }
         top = base;
-        // Stage the batch in LDS, cells first and bodies after them: every lane then reads entry
-        // j with the same address (an LDS broadcast), which keeps the per-node data off the
-        // vector ALU's lane-read path, and each kind of node gets a loop without the other's code.
-        const bool is_body = (__float_as_uint(rec.w) & 0x80000000u) != 0u;
-        const uint64_t cellm = __builtin_amdgcn_ballot_w64(lane < c && !is_body);
-        const uint64_t bodym = __builtin_amdgcn_ballot_w64(lane < c && is_body);
-        const int ncell = (int)__popcll(cellm);
+        // Each popped node is first judged for the wave as a whole, by the distance of its centre
+        // of mass to the bounding box of the wave's targets (margins far above float rounding):
+        //   opened by every lane   -> its children go onto the stack right here, no visit;
+        //   accepted by every lane -> visited by a loop that only adds the force;
+        //   far from every lane    -> visited without the cutoff and prune tests;
+        // the remaining cells and the bodies take the full tests.  Only cells beyond the largest
+        // cutoff distance of the wave take the first two shortcuts, so neither the cutoff nor
+        // the pruning rule can apply to them.
+        const uint64_t cmask = c >= 64 ? ~0ull : ((1ull << c) - 1ull);  // lanes holding an entry
         const float ex = fmaxf(fmaxf(gx0 - rec.x, rec.x - gx1), 0.f), ey = fmaxf(fmaxf(gy0 - rec.y, rec.y - gy1), 0.f);
-        const bool all_far = (cellm & ~__builtin_amdgcn_ballot_w64(__builtin_fmaf(ex, ex, ey * ey) > safe2)) == 0ull;
-        const uint64_t mine = is_body ? bodym : cellm;
-        const int slot_j = (is_body ? ncell : 0) +
-                           (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
-        if (lane < c) {
+        const float fxm = fmaxf(rec.x - gx0, gx1 - rec.x), fym = fmaxf(rec.y - gy0, gy1 - rec.y);
+        const float dmin2 = __builtin_fmaf(ex, ex, ey * ey), dmax2 = __builtin_fmaf(fxm, fxm, fym * fym);
+        const uint64_t bodym = __builtin_amdgcn_ballot_w64((int)__float_as_uint(rec.w) < 0) & cmask;
+        const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~bodym;
+        const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < rec.w * 0.999f) & farm_all;
+        const uint64_t surem = __builtin_amdgcn_ballot_w64(dmin2 > rec.w * 1.001f) & farm_all;
+        const uint64_t farcm = farm_all & ~(openm | surem);
+        const uint64_t nearm = cmask & ~(bodym | farm_all);
+        if (openm != 0ull) {
+            // exclusive prefix of the child counts of the opened nodes, from the ballots of its bits
+            const uint32_t ncl = __builtin_amdgcn_inverse_ballot_w64(openm) ? (aux.x & 7u) : 0u;
+            const uint64_t b0 = __builtin_amdgcn_ballot_w64((ncl & 1u) != 0u);
+            const uint64_t b1 = __builtin_amdgcn_ballot_w64((ncl & 2u) != 0u);
+            const uint64_t b2 = __builtin_amdgcn_ballot_w64((ncl & 4u) != 0u);
+            const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                                 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
+                                 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+            const uint32_t cf = aux.x >> 3;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i)
+                if (i < ncl) {
+                    snode[top + off + i] = cf + i;
+                    smask[top + off + i] = um;
+                }
+            top += (int)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2));
+            if (STATS) {
+                n_visit += (unsigned long long)__popcll(openm);
+                const uint64_t evals = __builtin_amdgcn_inverse_ballot_w64(openm) ? (uint64_t)__popcll(um) : 0ull;
+                unsigned long long e = evals;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                    e += __shfl_xor(e, o);
+                n_eval += e;
+            }
+        }
+        // Stage the rest in LDS, by kind: every lane then reads entry j with the same address (an
+        // LDS broadcast), which keeps the per-node data off the vector ALU's lane-read path, and
+        // each kind of node gets a loop without the other kinds' code.
+        const int nsure = (int)__popcll(surem), nfar = nsure + (int)__popcll(farcm), ncell = nfar + (int)__popcll(nearm);
+        const int cstaged = ncell + (int)__popcll(bodym);
+        int slot_j;
+        {
+            const int r_sure = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(surem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)surem, 0u));
+            const int r_far = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(farcm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)farcm, 0u));
+            const int r_near = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nearm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nearm, 0u));
+            const int r_body = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bodym >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bodym, 0u));
+            slot_j = r_sure;
+            slot_j = __builtin_amdgcn_inverse_ballot_w64(farcm) ? nsure + r_far : slot_j;
+            slot_j = __builtin_amdgcn_inverse_ballot_w64(nearm) ? nfar + r_near : slot_j;
+            slot_j = __builtin_amdgcn_inverse_ballot_w64(bodym) ? ncell + r_body : slot_j;
+        }
+        const bool staged = __builtin_amdgcn_inverse_ballot_w64(cmask & ~openm);
+        if (staged) {
             batch[slot_j][0] = make_uint4(__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z),
                                           __float_as_uint(rec.w));
             batch[slot_j][1] = make_uint4((uint32_t)um, (uint32_t)(um >> 32), aux.x, aux.y);
@@ -1005,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         // node index of batch entry j (only the rare FP64 re-decisions need it)
         auto node_of = [&](int j) {
             j = __builtin_amdgcn_readfirstlane(j);  // opaque: keeps a running copy of slot_j - j out of the loop
-            const uint64_t at = __builtin_amdgcn_ballot_w64(lane < c && slot_j == j);
+            const uint64_t at = __builtin_amdgcn_ballot_w64(staged && slot_j == j);
             return (uint32_t)__builtin_amdgcn_readlane((int)u, (int)__builtin_ctzll(at));
         };
         // Per-lane conditions are kept as 64-bit lane masks in scalar registers (the result of a
@@ -1081,15 +1134,32 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                 n_visit += 1;
             }
         };
-        if (all_far) {
-            for (int j = 0; j < ncell; ++j)
-                visit_cell(j, std::true_type{});
-        } else {
-            for (int j = 0; j < ncell; ++j)
-                visit_cell(j, std::false_type{});
+        // ---- cells every lane accepts: only the force, for the lanes the cell is visited for ----
+        for (int j = 0; j < nsure; ++j) {
+            const uint4 r = batch[j][0];
+            const uint2 q = *(const uint2 *)&batch[j][1];
+            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
+            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
+            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
+            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi;
+            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+#ifndef NB_ABL_NOFORCE
+            const float sc = __builtin_amdgcn_inverse_ballot_w64(mj) ? force_scale<MODE>(d2, __uint_as_float(r.z), eps2, eps3) : 0.f;
+            fx = __builtin_fmaf(dx, sc, fx);
+            fy = __builtin_fmaf(dy, sc, fy);
+#endif
+            if (STATS) {
+                n_eval += (unsigned long long)__popcll(mj);
+                n_acc += (unsigned long long)__popcll(mj);
+                n_visit += 1;
+            }
         }
+        for (int j = nsure; j < nfar; ++j)
+            visit_cell(j, std::true_type{});
+        for (int j = nfar; j < ncell; ++j)
+            visit_cell(j, std::false_type{});
         // ---- bodies: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
-        for (int j = ncell; j < c; ++j) {
+        for (int j = ncell; j < cstaged; ++j) {
             const uint4 r = batch[j][0];
             const uint2 q = *(const uint2 *)&batch[j][1];
             const float nx = __uint_as_float(r.x), ny = __uint_as_float(r.y), nm = __uint_as_float(r.z);
