@@ -14,7 +14,7 @@ namespace nb {
 
 constexpr int BH_KEY_LEVELS = 31;  // 2 bits per level in a 62-bit key
 constexpr int BH_MAX_DEPTH = 34;   // tree levels the build loops over (31 cell levels, leaves, spare)
-constexpr int BH_SCAN_BLOCKS = 512;
+constexpr int BH_SCAN_BLOCKS = 1024;
 
 struct BhBuffers {
     int n = 0;
