@@ -88,7 +88,12 @@ typedef struct nb_params {
     double collision_th;  /* COLLISION_TH 1.0e10: pairs closer than r_i + r_j + this are skipped */
     double bbox_margin;   /* the 1.0e10 pad added round the bounding box (barnesHut.cpp:28-31) */
     int integrator;       /* nb_integrator; 0 = the reference's scheme */
-    int reserved_;
+    int bucket_depth;     /* Barnes-Hut tree: 0 = one body per leaf at any depth, the reference's CPU tree
+                           * (src/cpu/quadtree.cpp:73-144).  k = 1..31 = the tree of the reference's GPU program
+                           * (src/gpu/BH/barnesHut_kernel.cu:290-423; k = 9 there): cells are not split below
+                           * level k, every leaf acts as one point mass at its bodies' centre of mass under the
+                           * cell rule 2 r_i + collision_th, the root box is rounded as that program rounds it,
+                           * and static bodies are not advanced. */
 } nb_params;
 
 /* NB_INT_EULER is the reference's update (v += a dt, then x += v dt: semi-implicit Euler,

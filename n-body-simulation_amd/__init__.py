@@ -59,7 +59,7 @@ class Params(C.Structure):
         ("collision_th", C.c_double),
         ("bbox_margin", C.c_double),
         ("integrator", C.c_int),
-        ("reserved_", C.c_int),
+        ("bucket_depth", C.c_int),
     ]
 
 

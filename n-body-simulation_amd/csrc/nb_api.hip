@@ -153,6 +153,7 @@ IntegrateArgs integrate_args(const nb_sim *s, int do_integrate)
     ia.dt_kick = (s->p.integrator == NB_INT_LEAPFROG && s->first_kick) ? 0.5 * s->p.dt : s->p.dt;
     ia.inv_len_unit = 1.0 / s->units.len_unit;
     ia.do_integrate = do_integrate;
+    ia.static_fixed = (s->alg == NB_ALG_BARNES_HUT && s->p.bucket_depth > 0) ? 1 : 0;
     return ia;
 }
 
@@ -175,6 +176,7 @@ BhStepArgs bh_args(nb_sim *s, int do_integrate)
     a.theta = s->p.theta;
     a.bbox_margin = s->p.bbox_margin;
     a.collision_th = s->p.collision_th;
+    a.bucket_depth = s->p.bucket_depth;
     a.collect_stats = s->collect_stats;
     return a;
 }
@@ -296,6 +298,10 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
     if (!(s->p.theta >= 0) || !(s->p.collision_th >= 0) || !(s->p.eps >= 0)) {
         delete s;
         return fail(NB_ERR_ARG, "nb_create: theta, collision_th and eps must be >= 0");
+    }
+    if (s->p.bucket_depth < 0 || s->p.bucket_depth > 31) {
+        delete s;
+        return fail(NB_ERR_ARG, "nb_create: bucket_depth must be 0..31");
     }
     if (s->p.integrator != NB_INT_EULER && s->p.integrator != NB_INT_LEAPFROG) {
         delete s;

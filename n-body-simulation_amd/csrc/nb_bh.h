@@ -65,6 +65,7 @@ struct BhStepArgs {
     double theta;
     double bbox_margin;
     double collision_th;
+    int bucket_depth;  // 0: one body per leaf; k: leaves are the cells of level k (point masses)
     int collect_stats;
 };
 

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const double2 *pos, int n,
     }
 }
 
-__global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk, double margin, double *box)
+__global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk, double margin, int gpu_rounding,
+                                                    double *box)
 {
     double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
     for (int i = threadIdx.x; i < nblk; i += 256) {
@@ -150,6 +151,14 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         }
         // fminf/fmaxf of the reference round every candidate to float (barnesHut.cpp:28-31);
         // rounding is monotone, so rounding the extreme gives the same box.
+        if (gpu_rounding) {
+            // the GPU program reduces the positions through fminf/fmaxf first and pads afterwards
+            // (barnesHut_kernel.cu:94-108): two roundings per bound
+            mnx = (double)(float)mnx;
+            mxx = (double)(float)mxx;
+            mny = (double)(float)mny;
+            mxy = (double)(float)mxy;
+        }
         box[0] = (double)(float)(mnx - margin);  // topLeft.x
         box[1] = (double)(float)(mxy + margin);  // topLeft.y
         box[2] = (double)(float)(mxx + margin);  // botRight.x
@@ -163,7 +172,8 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     if (blocks > BBOX_BLOCKS)
         blocks = BBOX_BLOCKS;
     hipLaunchKernelGGL(k_bbox_partial, dim3(blocks), dim3(256), 0, s, a.pos, a.n, b.bbox_part);
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, b.box);
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin,
+                       a.bucket_depth > 0 ? 1 : 0, b.box);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -172,7 +182,9 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // Digit of level l (0 = the root's split) occupies bits [61-2l, 60-2l]:
 // 2*(below the y midpoint) + (right of the x midpoint), i.e. TL=0, TR=1, BL=2, BR=3.
-__global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const double *box, uint64_t *keys,
+// Only the first `levels` digits are computed, the rest of the key is zero: bodies of one cell
+// of that level then share a key and end up in one leaf.
+__global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const double *box, int levels, uint64_t *keys,
                                               uint32_t *idx)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const d
     const double2 p = pos[i];
     uint64_t k = 0;
 #pragma unroll 1
-    for (int l = 0; l < BH_KEY_LEVELS; ++l) {
+    for (int l = 0; l < levels; ++l) {
         const double mx = (tlx + brx) / 2.0, my = (tly + bry) / 2.0;
         const bool right = !(mx >= p.x);  // getQuadrant: mid >= x is the left half
         const bool below = !(my <= p.y);  // mid <= y is the top half
@@ -192,13 +204,14 @@ __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const d
         bry = below ? bry : my;
         k = (k << 2) | ((uint64_t)below << 1) | (uint64_t)right;
     }
-    keys[i] = k;
+    keys[i] = k << (2 * (BH_KEY_LEVELS - levels));
     idx[i] = (uint32_t)i;
 }
 
 int bh_keys(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
-    hipLaunchKernelGGL(k_keys, dim3((a.n + 255) / 256), dim3(256), 0, s, a.pos, a.n, b.box, b.keys[0], b.idx[0]);
+    hipLaunchKernelGGL(k_keys, dim3((a.n + 255) / 256), dim3(256), 0, s, a.pos, a.n, b.box,
+                       a.bucket_depth > 0 ? a.bucket_depth : BH_KEY_LEVELS, b.keys[0], b.idx[0]);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -395,7 +408,9 @@ int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     const int n = a.n;
     const int nblk = b.sort_blocks;
     int cur = 0;
-    for (int shift = 0; shift < KEY_BITS; shift += SORT_BITS) {
+    // keys cut off at a bucket depth have only zeros below it: passes over those digits change nothing
+    const int zero_bits = a.bucket_depth > 0 ? KEY_BITS - 2 * a.bucket_depth : 0;
+    for (int shift = zero_bits / SORT_BITS * SORT_BITS; shift < KEY_BITS; shift += SORT_BITS) {
         hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, s, b.keys[cur], n, shift, b.hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(SORT_BINS), dim3(256), 0, s, b.hist, nblk, b.hist_totals);
         hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, s, b.keys[cur], b.idx[cur], b.keys[cur ^ 1],
@@ -712,6 +727,7 @@ struct ComArgs {
     float4 *node_rec;
     uint2 *node_aux;
     double inv_len, inv_mass, theta, cth;
+    int bucket;  // leaves are point masses judged like cells (the GPU program's tree)
 };
 
 // Centres of mass, masses and traversal records of the nodes of tree level d (children first:
@@ -755,6 +771,13 @@ __device__ __forceinline__ void com_level(const ComArgs &a, int d)
                 rec = make_float4((float)(cx * a.inv_len), (float)(cy * a.inv_len), (float)(mtot * a.inv_mass),
                                   -(float)((rmax + a.cth) * a.inv_len));
                 width = -rmax;
+            }
+            if (a.bucket) {
+                // a cell of zero width: accepted from any distance > 0, then subject to the cell
+                // rule 2 r_i + collision_th (ComputeForce, barnesHut_kernel.cu:387-399); the target's
+                // own one-body leaf (distance 0) is "opened" and has no children
+                rec.w = 0.f;
+                width = 0.0;
             }
         } else {
             // updateCenterMass: total = sum of child masses, com = sum(child com * child mass) / total,
@@ -826,6 +849,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.inv_mass = 1.0 / a.units.mass_unit;
     c.theta = a.theta;
     c.cth = a.collision_th;
+    c.bucket = a.bucket_depth > 0 ? 1 : 0;
     // levels beyond the ones the build launched per-level kernels for: one block, one launch
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
@@ -1225,7 +1249,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     }
     // a static body keeps the acceleration it was given (calculateAcceleration, barnesHut.cpp:96-106)
     // and every body is advanced with its own velocity (barnesHut.cpp:108-123)
-    if (a.ia.do_integrate) {
+    if (a.ia.do_integrate && (dynamic || !a.ia.static_fixed)) {
         const double2 aa = dynamic ? make_double2(ax, ay) : a.acc[body];
         double2 v = a.vel[body];
         double2 p = pd;

@@ -53,6 +53,7 @@ struct IntegrateArgs {
     double dt_kick;  // kick: v += a dt_kick (dt, or dt/2 on the first leapfrog step)
     double inv_len_unit;
     int do_integrate;  // 0: only store accelerations
+    int static_fixed;  // 1: bodies that are not dynamic keep their position and velocity
 };
 
 // ---- direct sum (nb_direct.hip) ----

@@ -69,7 +69,7 @@ extern "C" void nb_default_params(nb_params *p)
     p->collision_th = 1.0e10;
     p->bbox_margin = 1.0e10;
     p->integrator = NB_INT_EULER;
-    p->reserved_ = 0;
+    p->bucket_depth = 0;
 }
 
 extern "C" int nb_init_scenario(int sim, int n, unsigned seed, nb_body *out)

@@ -464,3 +464,163 @@ void orc_morton_keys(int n, const orc_body *b, const double *box, uint64_t *keys
         keys[i] = k;
     }
 }
+
+/* ---------------------------------------------------------------- the GPU program's tree */
+
+/* ComputeBoundingBoxKernel, barnesHut_kernel.cu:62-111: positions are reduced through
+ * fminf/fmaxf (rounded to float), then padded, then reduced through fminf/fmaxf again. */
+void orc_bh_gpu_bbox(const orc_params *p, int n, const orc_body *b, double *box)
+{
+    float mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+        mnx = fminf(mnx, (float)b[i].px);
+        mxx = fmaxf(mxx, (float)b[i].px);
+        mny = fminf(mny, (float)b[i].py);
+        mxy = fmaxf(mxy, (float)b[i].py);
+    }
+    box[0] = (float)((double)mnx - p->bbox_margin);
+    box[1] = (float)((double)mxy + p->bbox_margin);
+    box[2] = (float)((double)mxx + p->bbox_margin);
+    box[3] = (float)((double)mny - p->bbox_margin);
+}
+
+typedef struct gnode {
+    double cmx, cmy, mass;
+    int leaf;
+    int child[4]; /* in the order ComputeForce visits them: 4i+1 TR, 4i+2 TL, 4i+3 BL, 4i+4 BR; -1 = empty */
+} gnode;
+
+typedef struct gtree {
+    gnode *nd;
+    int count, cap;
+    int *scratch;
+} gtree;
+
+/* ConstructQuadTreeKernel, :290-360, for the bodies ids[0..cnt) (kept in index order). */
+static int gt_build(gtree *t, const orc_body *b, int *ids, int cnt, double tlx, double tly, double brx, double bry,
+                    int level, int depth)
+{
+    if (t->count == t->cap) {
+        t->cap = t->cap ? t->cap * 2 : 1024;
+        t->nd = (gnode *)realloc(t->nd, sizeof(gnode) * (size_t)t->cap);
+    }
+    const int ni = t->count++;
+    double M = 0.0, rx = 0.0, ry = 0.0;
+    for (int k = 0; k < cnt; ++k) {
+        const orc_body *q = &b[ids[k]];
+        M += q->mass;
+        rx += q->mass * q->px;
+        ry += q->mass * q->py;
+    }
+    t->nd[ni].mass = M;
+    t->nd[ni].cmx = rx / M;
+    t->nd[ni].cmy = ry / M;
+    t->nd[ni].leaf = 1;
+    for (int c = 0; c < 4; ++c)
+        t->nd[ni].child[c] = -1;
+    if (level >= depth || cnt == 1)
+        return ni;
+    t->nd[ni].leaf = 0;
+    /* getQuadrant :118-147: 1 TR, 2 TL, 3 BL, 4 BR; stable grouping */
+    const double mx = (tlx + brx) / 2, my = (tly + bry) / 2;
+    int cnt4[4] = {0, 0, 0, 0};
+    int *quad = (int *)malloc(sizeof(int) * (size_t)cnt);
+    for (int k = 0; k < cnt; ++k) {
+        const orc_body *q = &b[ids[k]];
+        int c;
+        if (mx >= q->px)
+            c = (my <= q->py) ? 1 : 2; /* slot of TL, BL in visiting order */
+        else
+            c = (my <= q->py) ? 0 : 3; /* TR, BR */
+        quad[k] = c;
+        cnt4[c]++;
+    }
+    int start[4], fill[4];
+    start[0] = 0;
+    for (int c = 1; c < 4; ++c)
+        start[c] = start[c - 1] + cnt4[c - 1];
+    for (int c = 0; c < 4; ++c)
+        fill[c] = start[c];
+    int *tmp = (int *)malloc(sizeof(int) * (size_t)cnt);
+    for (int k = 0; k < cnt; ++k)
+        tmp[fill[quad[k]]++] = ids[k];
+    memcpy(ids, tmp, sizeof(int) * (size_t)cnt);
+    free(tmp);
+    free(quad);
+    for (int c = 0; c < 4; ++c) {
+        if (cnt4[c] == 0)
+            continue;
+        double ctlx, ctly, cbrx, cbry; /* UpdateChildBound :149-172 */
+        if (c == 0) { ctlx = mx; ctly = tly; cbrx = brx; cbry = my; }
+        else if (c == 1) { ctlx = tlx; ctly = tly; cbrx = mx; cbry = my; }
+        else if (c == 2) { ctlx = tlx; ctly = my; cbrx = mx; cbry = bry; }
+        else { ctlx = mx; ctly = my; cbrx = brx; cbry = bry; }
+        const int ch = gt_build(t, b, ids + start[c], cnt4[c], ctlx, ctly, cbrx, cbry, level + 1, depth);
+        t->nd[ni].child[c] = ch;
+    }
+    return ni;
+}
+
+/* ComputeForce, :378-423 (acceleration = force / m_i). */
+static void gt_force(const orc_params *p, const gtree *t, int ni, const orc_body *bi, double width, double *ax, double *ay)
+{
+    if (ni < 0)
+        return;
+    const gnode *q = &t->nd[ni];
+    const double dist = dist2d(bi->px, bi->py, q->cmx, q->cmy);
+    const int collide = bi->radius * 2 + p->collision_th > dist;
+    if (!q->leaf && !(width / dist < p->theta)) {
+        for (int c = 0; c < 4; ++c)
+            gt_force(p, t, q->child[c], bi, width / 2, ax, ay);
+        return;
+    }
+    if (!collide) {
+        const double rx = q->cmx - bi->px, ry = q->cmy - bi->py;
+        const double r = sqrt(rx * rx + ry * ry + p->eps * p->eps);
+        const double f = (p->gravity * bi->mass * q->mass) / (r * r * r + p->eps * p->eps);
+        *ax += rx * f / bi->mass;
+        *ay += ry * f / bi->mass;
+    }
+}
+
+void orc_bh_gpu_accel(const orc_params *p, int n, const orc_body *b, int depth, double *acc)
+{
+    double box[4];
+    orc_bh_gpu_bbox(p, n, b, box);
+    gtree t = {0};
+    int *ids = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i)
+        ids[i] = i;
+    gt_build(&t, b, ids, n, box[0], box[1], box[2], box[3], 0, depth);
+    const double width = box[2] - box[0];
+    for (int i = 0; i < n; ++i) {
+        double ax = b[i].ax, ay = b[i].ay;
+        if (b[i].is_dynamic) {
+            ax = ay = 0.0;
+            gt_force(p, &t, 0, &b[i], width, &ax, &ay);
+        }
+        acc[2 * i] = ax;
+        acc[2 * i + 1] = ay;
+    }
+    free(ids);
+    free(t.nd);
+}
+
+void orc_bh_gpu_step(const orc_params *p, int n, orc_body *b, int depth, int nsteps)
+{
+    double *acc = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    for (int s = 0; s < nsteps; ++s) {
+        orc_bh_gpu_accel(p, n, b, depth, acc);
+        for (int i = 0; i < n; ++i) {
+            if (!b[i].is_dynamic)
+                continue;
+            b[i].ax = acc[2 * i];
+            b[i].ay = acc[2 * i + 1];
+            b[i].vx += b[i].ax * p->dt;
+            b[i].vy += b[i].ay * p->dt;
+            b[i].px += b[i].vx * p->dt;
+            b[i].py += b[i].vy * p->dt;
+        }
+    }
+    free(acc);
+}

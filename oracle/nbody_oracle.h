@@ -52,6 +52,19 @@ int orc_bh_accel(const orc_params *p, int n, const orc_body *b, double *acc, dou
 /* nsteps of BarnesHut::update on b in place; returns 0 or -1 as above. */
 int orc_bh_step(const orc_params *p, int n, orc_body *b, int nsteps);
 
+/* The tree of the reference's GPU program (src/gpu/BH/barnesHut_kernel.cu), restated on the CPU
+ * in FP64: root box as ComputeBoundingBoxKernel rounds it (:62-111), cells split by getQuadrant
+ * (:118-147) down to level `depth` (9 in the reference: MAX_NODES 349525), a cell with one body or
+ * on the last level is a leaf, every node's centre of mass is the mass-weighted mean of its bodies
+ * (:196-243, summed here in index order; the reference's order depends on atomics), forces by
+ * ComputeForce (:378-423): a leaf acts unless 2 r_i + th > dist, a cell with width/dist < theta
+ * likewise, other cells are opened.  No output of that program exists to pin this restatement
+ * (it cannot be built here): parity unpinned. */
+void orc_bh_gpu_bbox(const orc_params *p, int n, const orc_body *b, double *box);
+void orc_bh_gpu_accel(const orc_params *p, int n, const orc_body *b, int depth, double *acc);
+/* nsteps of the GPU program's update (only dynamic bodies are advanced, :431-443). */
+void orc_bh_gpu_step(const orc_params *p, int n, orc_body *b, int depth, int nsteps);
+
 /* 2x31-bit quadrant path of each body by the reference's midpoint descent from box:
  * digit at level l (0 = root split) sits in bits [61-2l, 60-2l] and is
  * 2*(below the y midpoint) + (right of the x midpoint). */

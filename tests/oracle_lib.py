@@ -60,6 +60,9 @@ class Oracle:
         L.orc_bh_step.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int]
         L.orc_bh_step.restype = C.c_int
         L.orc_morton_keys.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bh_gpu_bbox.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_bh_gpu_accel.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_bh_gpu_step.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_int]
 
     def params(self, **kw):
         p = Params()
@@ -118,6 +121,24 @@ class Oracle:
         rc = self.lib.orc_bh_step(C.byref(p), len(b), _ptr(b), nsteps)
         if rc != 0:
             raise ValueError("coincident bodies")
+        return b
+
+    def gpu_bbox(self, b, p=None):
+        p = p or self.params()
+        box = np.zeros(4)
+        self.lib.orc_bh_gpu_bbox(C.byref(p), len(b), _ptr(b), _ptr(box))
+        return box
+
+    def gpu_accel(self, b, depth=9, p=None):
+        p = p or self.params()
+        acc = np.zeros((len(b), 2))
+        self.lib.orc_bh_gpu_accel(C.byref(p), len(b), _ptr(b), depth, _ptr(acc))
+        return acc
+
+    def gpu_step(self, b, nsteps, depth=9, p=None):
+        p = p or self.params()
+        b = b.copy()
+        self.lib.orc_bh_gpu_step(C.byref(p), len(b), _ptr(b), depth, nsteps)
         return b
 
     def morton_keys(self, b, box):
