@@ -172,11 +172,14 @@ enum nb_debug_array {
                                body's radius there (sign bit set, -0.0 for radius 0) */
     NB_DBG_LEVEL_START = 7, /* 65 uint32: first node of each tree level, then total */
     NB_DBG_ORDER = 8,       /* n uint32: caller index of the body at each exchange-order slot */
-    NB_DBG_COUNTERS = 9     /* 8 uint64: [0] body-node evaluations, [1] accepted interactions,
+    NB_DBG_COUNTERS = 9,    /* 8 uint64: [0] body-node evaluations, [1] accepted interactions,
                                [2] nodes, [3] tree levels, [4] node visits re-decided in FP64,
                                [5] node visits summed over the 64-body groups, [6] node batches fetched,
                                [7] deepest traversal stack,
                                of the last Barnes-Hut step run with stage timing on */
+    NB_DBG_KEY_LEVELS = 10  /* 2 uint32: [0] the first tree level whose cells no body can open (wider cutoff
+                               than opening distance; 32 = none), [1] the number of levels the keys hold:
+                               bodies that share a cell of that level share a leaf */
 };
 /* Copies the array into out (bytes = capacity of out); *written gets the size. */
 int nb_debug_read(nb_sim *sim, int which, void *out, size_t bytes, size_t *written);

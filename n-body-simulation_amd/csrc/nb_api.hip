@@ -721,6 +721,10 @@ int nb_debug_read(nb_sim *s, int which, void *out, size_t bytes, size_t *written
         if (written)
             *written = need;
         return NB_OK;
+    case NB_DBG_KEY_LEVELS:
+        src = s->bh.cut;
+        need = sizeof(uint32_t) * 2;
+        break;
     case NB_DBG_COUNTERS:
         src = s->bh.counters;
         need = sizeof(unsigned long long) * 8;

@@ -23,10 +23,13 @@ struct BhBuffers {
     double *bbox_part = nullptr;  // per-block partial min/max
     uint64_t *keys[2] = {nullptr, nullptr};
     uint32_t *idx[2] = {nullptr, nullptr};
-    int sorted = 0;               // which of the two holds the sorted result
+    int sorted = 0;               // which of the two holds the sorted result (always 0: see bh_sort)
+    uint32_t *cut = nullptr;      // [0] first tree level whose cells are never opened (32: none),
+                                  // [1] levels the keys are computed to
     uint32_t *hist = nullptr;     // 256 x sort blocks
     uint32_t *hist_totals = nullptr;  // 256: keys per digit of the current pass
     int sort_blocks = 0;
+    double *leaf_sum = nullptr;   // 4 doubles per sorted body: sums over the run of equal keys starting there
     float4 *posm_s = nullptr;     // per sorted body {x, y, m, radius} in internal units
     uint4 *node_meta = nullptr;   // first body, body count, first child, child count | cell level << 8
     uint4 *split = nullptr;       // per frontier slot: the three quadrant boundaries and child count

@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const double2 *pos, int n,
     }
 }
 
-__global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk, double margin, int gpu_rounding,
-                                                    double *box)
+__global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk, double margin, int bucket_depth,
+                                                    double theta, double cth, double *box, uint32_t *cut)
 {
     double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
     for (int i = threadIdx.x; i < nblk; i += 256) {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         }
         // fminf/fmaxf of the reference round every candidate to float (barnesHut.cpp:28-31);
         // rounding is monotone, so rounding the extreme gives the same box.
-        if (gpu_rounding) {
+        if (bucket_depth > 0) {
             // the GPU program reduces the positions through fminf/fmaxf first and pads afterwards
             // (barnesHut_kernel.cu:94-108): two roundings per bound
             mnx = (double)(float)mnx;
@@ -163,6 +163,27 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         box[1] = (double)(float)(mxy + margin);  // topLeft.y
         box[2] = (double)(float)(mxx + margin);  // botRight.x
         box[3] = (double)(float)(mny - margin);  // botRight.y
+        // First level whose cells no body ever opens: a cell is opened by a body that neither
+        // accepts it (dist <= width / theta) nor sees it wholly inside its cutoff distance
+        // (dist >= collision_th - diagonal); when width / theta < collision_th - diagonal no
+        // distance does both.  What lies below such a cell is never looked at, so the tree is
+        // not built there and the keys stop at that level.  The margins (1e-4 each side) cover
+        // the float rounding of the two thresholds the traversal compares.
+        uint32_t first_closed = 32u;
+        if (bucket_depth == 0) {
+            const double w0 = box[2] - box[0], h0 = box[1] - box[3];
+            for (int l = BH_KEY_LEVELS; l >= 0; --l) {
+                const double w = ldexp(w0, -l), h = ldexp(h0, -l);
+                const double reach = cth * (1.0 - 1.0e-4) - sqrt(w * w + h * h);
+                if (reach > 0.0 && reach * (1.0 - 1.0e-4) > w / theta)
+                    first_closed = (uint32_t)l;
+                else
+                    break;  // cells only grow from here up
+            }
+        }
+        cut[0] = first_closed;
+        cut[1] = bucket_depth > 0 ? (uint32_t)bucket_depth
+                                  : (first_closed < (uint32_t)BH_KEY_LEVELS ? first_closed : (uint32_t)BH_KEY_LEVELS);
     }
 }
 
@@ -172,8 +193,8 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     if (blocks > BBOX_BLOCKS)
         blocks = BBOX_BLOCKS;
     hipLaunchKernelGGL(k_bbox_partial, dim3(blocks), dim3(256), 0, s, a.pos, a.n, b.bbox_part);
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin,
-                       a.bucket_depth > 0 ? 1 : 0, b.box);
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, a.bucket_depth,
+                       a.theta, a.collision_th, b.box, b.cut);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -182,14 +203,18 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // Digit of level l (0 = the root's split) occupies bits [61-2l, 60-2l]:
 // 2*(below the y midpoint) + (right of the x midpoint), i.e. TL=0, TR=1, BL=2, BR=3.
-// Only the first `levels` digits are computed, the rest of the key is zero: bodies of one cell
-// of that level then share a key and end up in one leaf.
-__global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const double *box, int levels, uint64_t *keys,
-                                              uint32_t *idx)
+// Only the first cut[1] digits are computed, the rest of the key is zero: bodies of one cell of
+// that level then share a key and end up in one leaf.  The keys go to the buffer the first sort
+// pass that has work reads from (see bh_sort).
+__device__ __forceinline__ int first_sort_pass(uint32_t key_levels);
+
+__global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const double *box, const uint32_t *cut,
+                                              uint64_t *keys0, uint64_t *keys1, uint32_t *idx0, uint32_t *idx1)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n)
         return;
+    const int levels = (int)cut[1];
     double tlx = box[0], tly = box[1], brx = box[2], bry = box[3];
     const double2 p = pos[i];
     uint64_t k = 0;
@@ -204,14 +229,15 @@ __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const d
         bry = below ? bry : my;
         k = (k << 2) | ((uint64_t)below << 1) | (uint64_t)right;
     }
-    keys[i] = k << (2 * (BH_KEY_LEVELS - levels));
-    idx[i] = (uint32_t)i;
+    const bool odd = first_sort_pass((uint32_t)levels) & 1;
+    (odd ? keys1 : keys0)[i] = levels > 0 ? k << (2 * (BH_KEY_LEVELS - levels)) : 0ull;
+    (odd ? idx1 : idx0)[i] = (uint32_t)i;
 }
 
 int bh_keys(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
-    hipLaunchKernelGGL(k_keys, dim3((a.n + 255) / 256), dim3(256), 0, s, a.pos, a.n, b.box,
-                       a.bucket_depth > 0 ? a.bucket_depth : BH_KEY_LEVELS, b.keys[0], b.idx[0]);
+    hipLaunchKernelGGL(k_keys, dim3((a.n + 255) / 256), dim3(256), 0, s, a.pos, a.n, b.box, b.cut, b.keys[0], b.keys[1],
+                       b.idx[0], b.idx[1]);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -226,9 +252,26 @@ constexpr int SORT_TILE = 256 * SORT_ITEMS;
 constexpr int SORT_BITS = 8;
 constexpr int SORT_BINS = 1 << SORT_BITS;
 constexpr int KEY_BITS = 2 * BH_KEY_LEVELS;
+constexpr int SORT_PASSES = (KEY_BITS + SORT_BITS - 1) / SORT_BITS;
 
-__global__ __launch_bounds__(256) void k_sort_count(const uint64_t *keys, int n, int shift, uint32_t *hist, int nblk)
+// Keys computed to `key_levels` digits are zero in their low KEY_BITS - 2 key_levels bits; a
+// sort pass whose digit lies wholly in there would move nothing and returns at once.  Pass p
+// reads buffer p & 1 and writes the other, so the last pass always leaves the result in
+// buffer 0 and the keys are written where the first pass with work reads them: the host
+// launches the same kernels every step and never needs to know how many did anything.
+__device__ __forceinline__ int first_sort_pass(uint32_t key_levels)
 {
+    const int zero_bits = KEY_BITS - 2 * (int)key_levels;
+    const int p = zero_bits / SORT_BITS;
+    return p < SORT_PASSES - 1 ? p : SORT_PASSES - 1;
+}
+
+__global__ __launch_bounds__(256) void k_sort_count(const uint64_t *keys, int n, int pass, const uint32_t *cut,
+                                                    uint32_t *hist, int nblk)
+{
+    if (pass < first_sort_pass(cut[1]))
+        return;
+    const int shift = pass * SORT_BITS;
     __shared__ uint32_t h[SORT_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -281,8 +324,11 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *data, int count)
 
 // Sort pass, step 2: one block per digit.  Exclusive scan of the digit's per-block counts in
 // place (hist[d][0..nblk)), and the digit's total into totals[d].
-__global__ __launch_bounds__(256) void k_scan_rows(uint32_t *hist, int nblk, uint32_t *totals)
+__global__ __launch_bounds__(256) void k_scan_rows(uint32_t *hist, int nblk, uint32_t *totals, int pass,
+                                                   const uint32_t *cut)
 {
+    if (pass < first_sort_pass(cut[1]))
+        return;
     uint32_t *row = hist + (size_t)blockIdx.x * nblk;
     uint32_t running = 0;
     for (int base = 0; base < nblk; base += 256) {
@@ -302,9 +348,13 @@ __global__ __launch_bounds__(256) void k_scan_rows(uint32_t *hist, int nblk, uin
 // 64*SORT_ITEMS keys and ranks them sub-round by sub-round against its own LDS counters
 // (no block barrier inside), so the order inside a digit is the input order.
 __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, const uint32_t *idx_in,
-                                                      uint64_t *keys_out, uint32_t *idx_out, int n, int shift,
-                                                      const uint32_t *hist, int nblk, const uint32_t *totals)
+                                                      uint64_t *keys_out, uint32_t *idx_out, int n, int pass,
+                                                      const uint32_t *cut, const uint32_t *hist, int nblk,
+                                                      const uint32_t *totals)
 {
+    if (pass < first_sort_pass(cut[1]))
+        return;
+    const int shift = pass * SORT_BITS;
     __shared__ uint32_t wcnt[4][SORT_BINS];
     __shared__ uint32_t dbase[SORT_BINS];
     __shared__ uint32_t lstart[SORT_BINS];
@@ -407,16 +457,15 @@ int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     const int n = a.n;
     const int nblk = b.sort_blocks;
-    int cur = 0;
-    // keys cut off at a bucket depth have only zeros below it: passes over those digits change nothing
-    const int zero_bits = a.bucket_depth > 0 ? KEY_BITS - 2 * a.bucket_depth : 0;
-    for (int shift = zero_bits / SORT_BITS * SORT_BITS; shift < KEY_BITS; shift += SORT_BITS) {
-        hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, s, b.keys[cur], n, shift, b.hist, nblk);
-        hipLaunchKernelGGL(k_scan_rows, dim3(SORT_BINS), dim3(256), 0, s, b.hist, nblk, b.hist_totals);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, s, b.keys[cur], b.idx[cur], b.keys[cur ^ 1],
-                           b.idx[cur ^ 1], n, shift, b.hist, nblk, b.hist_totals);
-        cur ^= 1;
+    for (int pass = 0; pass < SORT_PASSES; ++pass) {
+        const int in = pass & 1, out = in ^ 1;
+        hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, s, b.keys[in], n, pass, b.cut, b.hist, nblk);
+        hipLaunchKernelGGL(k_scan_rows, dim3(SORT_BINS), dim3(256), 0, s, b.hist, nblk, b.hist_totals, pass, b.cut);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, s, b.keys[in], b.idx[in], b.keys[out], b.idx[out], n,
+                           pass, b.cut, b.hist, nblk, b.hist_totals);
     }
+    static_assert(SORT_PASSES % 2 == 0, "the last pass must write buffer 0");
+    const int cur = 0;
     b.sorted = cur;
     hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, s, b.idx[cur], n, a.pos, a.mass, a.radius,
                        1.0 / a.units.len_unit, 1.0 / a.units.mass_unit, b.posm_s);
@@ -726,9 +775,155 @@ struct ComArgs {
     double *node_com;
     float4 *node_rec;
     uint2 *node_aux;
+    const uint32_t *cut;
+    const double *leaf_sum;  // per sorted position: sums of the run of equal keys that starts there
     double inv_len, inv_mass, theta, cth;
     int bucket;  // leaves are point masses judged like cells (the GPU program's tree)
 };
+
+// Traversal record, width and prune threshold of a cell of level lvl with the given centre of mass.
+__device__ __forceinline__ void cell_record(const ComArgs &a, double cx, double cy, double mtot, int lvl, double width0,
+                                            float4 &rec, double &width, float &prune)
+{
+    width = ldexp(width0, -lvl);
+    const double wt = width * a.inv_len / a.theta;  // width / dist < theta  <=>  dist > width / theta
+    rec = make_float4((float)(cx * a.inv_len), (float)(cy * a.inv_len), (float)(mtot * a.inv_mass), (float)(wt * wt));
+    // Prune threshold: the cell's centre of mass lies inside the cell, so every point of
+    // the cell is within dist(com) + diagonal of a target.  If that is below collision_th
+    // (less a margin for float rounding) nothing in the cell can contribute.
+    const double height = ldexp(a.box[1] - a.box[3], -lvl);
+    const double reach = a.cth * (1.0 - 1.0e-4) - sqrt(width * width + height * height);
+    prune = reach > 0.0 ? (float)((reach * a.inv_len) * (reach * a.inv_len)) : -1.f;
+}
+
+// Record of a leaf that holds several bodies (all with one key), from their sums.
+__device__ __forceinline__ void multi_body_record(const ComArgs &a, double sx, double sy, double mtot, double rmax,
+                                                  double width0, double &cx, double &cy, float4 &rec, double &width,
+                                                  float &prune)
+{
+    cx = sx / mtot;
+    cy = sy / mtot;
+    const uint32_t closed_level = a.cut[0];
+    if (closed_level <= (uint32_t)BH_KEY_LEVELS) {
+        // the bodies of a cell no body ever opens (see k_bbox_final): a cell record, no children
+        cell_record(a, cx, cy, mtot, (int)closed_level, width0, rec, width, prune);
+    } else {
+        // bodies at one position (equal in all 31 levels): they act as one body
+        rec = make_float4((float)(cx * a.inv_len), (float)(cy * a.inv_len), (float)(mtot * a.inv_mass),
+                          -(float)((rmax + a.cth) * a.inv_len));
+        width = -rmax;
+    }
+    if (a.bucket) {
+        // a cell of zero width: accepted from any distance > 0, then subject to the cell
+        // rule 2 r_i + collision_th (ComputeForce, barnesHut_kernel.cu:387-399)
+        rec.w = 0.f;
+        width = 0.0;
+    }
+}
+
+__device__ __forceinline__ void store_node(const ComArgs &a, uint32_t u, const uint4 meta, double cx, double cy, double mtot,
+                                           double width, float4 rec, float prune)
+{
+    double2 *o = (double2 *)a.node_com + 2 * (size_t)u;
+    o[0] = make_double2(cx, cy);
+    o[1] = make_double2(mtot, width);
+    a.node_rec[u] = rec;
+    a.node_aux[u] = make_uint2((meta.z << 3) | (meta.w & 0xffu), __float_as_uint(prune));
+}
+
+// Sums over every run of bodies with one key (= every leaf with several bodies), left at the
+// run's first sorted position as {sum m x, sum m y, sum m, max radius}.  One wave per 64
+// consecutive sorted bodies: a segmented scan inside the wave gives the runs that end in its
+// chunk; a run that goes on past the chunk is finished by the same wave, 64 bodies at a time
+// (the waves of the chunks it crosses skip those bodies).  The order of the additions is fixed
+// by the positions alone, so the sums are reproducible.
+__global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const uint32_t *idx, int n, const double2 *pos,
+                                                   const double *mass, const double *radius, double *leaf_sum)
+{
+    const int lane = lane_id();
+    const int chunk = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (chunk >= n)
+        return;
+    const int k = chunk + lane;
+    const bool valid = k < n;
+    const uint64_t key = valid ? keys[k] : ~0ull;
+    const uint64_t prev = (valid && k > 0) ? keys[k - 1] : ~0ull;  // ~0 is no key (62 bits)
+    double sm = 0.0, sx = 0.0, sy = 0.0, rm = 0.0;
+    if (valid) {
+        const uint32_t o = idx[k];
+        const double2 p = pos[o];
+        sm = mass[o];
+        sx = p.x * sm;
+        sy = p.y * sm;
+        rm = radius[o];
+    }
+    const uint64_t heads = __builtin_amdgcn_ballot_w64(valid && (k == 0 || key != prev));
+    // first lane of this lane's run, if the run starts in this chunk
+    const uint64_t upto = heads & ((2ull << lane) - 1ull);
+    const int start = upto ? 63 - __builtin_clzll(upto) : -1;
+    const int dist = start >= 0 ? lane - start : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double tm = __shfl_up(sm, o), tx = __shfl_up(sx, o), ty = __shfl_up(sy, o), tr = __shfl_up(rm, o);
+        if (o <= dist) {
+            sm += tm;
+            sx += tx;
+            sy += ty;
+            rm = fmax(rm, tr);
+        }
+    }
+    // last lane of each run inside the chunk: the next lane starts a run, or the chunk ends
+    const bool last_in_chunk = lane == 63 || !valid || ((heads >> (lane + 1)) & 1ull) || k + 1 >= n;
+    const bool ends = valid && start >= 0 && last_in_chunk;
+    // does the run of the chunk's last body go on in the next chunk?
+    const int tail = chunk + 64;
+    const uint64_t last_key = (uint64_t)__shfl(key, 63);
+    const bool goes_on = tail < n && keys[tail] == last_key;  // uniform
+    if (ends && !(lane == 63 && goes_on) && dist > 0) {
+        double *o = leaf_sum + 4 * (size_t)(chunk + start);
+        o[0] = sx;
+        o[1] = sy;
+        o[2] = sm;
+        o[3] = rm;
+    }
+    const int start63 = __shfl(start, 63);
+    if (goes_on && start63 >= 0) {
+        double am = __shfl(sm, 63), ax = __shfl(sx, 63), ay = __shfl(sy, 63), ar = __shfl(rm, 63);
+        for (int base = tail; base < n; base += 64) {
+            const int kk = base + lane;
+            const bool in = kk < n && keys[kk] == last_key;
+            double pm = 0.0, px = 0.0, py = 0.0, pr = 0.0;
+            if (in) {
+                const uint32_t o = idx[kk];
+                const double2 p = pos[o];
+                pm = mass[o];
+                px = p.x * pm;
+                py = p.y * pm;
+                pr = radius[o];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                pm += __shfl_xor(pm, o);
+                px += __shfl_xor(px, o);
+                py += __shfl_xor(py, o);
+                pr = fmax(pr, __shfl_xor(pr, o));
+            }
+            am += pm;
+            ax += px;
+            ay += py;
+            ar = fmax(ar, pr);
+            if (__builtin_amdgcn_ballot_w64(in) != ~0ull)
+                break;  // the run ended inside these 64
+        }
+        if (lane == 0) {
+            double *o = leaf_sum + 4 * (size_t)(chunk + start63);
+            o[0] = ax;
+            o[1] = ay;
+            o[2] = am;
+            o[3] = ar;
+        }
+    }
+}
 
 // Centres of mass, masses and traversal records of the nodes of tree level d (children first:
 // the caller goes through the levels bottom-up).
@@ -743,7 +938,7 @@ __device__ __forceinline__ void com_level(const ComArgs &a, int d)
         float4 rec;
         float prune = -1.f;
         if (nchild == 0) {
-            // a leaf: one body, or several bodies with the same 62-bit path taken as one
+            // a leaf: one body, or the bodies that share a key
             const uint32_t first = meta.x, count = meta.y;
             if (count == 1) {
                 const uint32_t o = a.idx[first];
@@ -754,30 +949,15 @@ __device__ __forceinline__ void com_level(const ComArgs &a, int d)
                 const float4 pm = a.posm_s[first];
                 rec = make_float4(pm.x, pm.y, pm.z, -(float)((a.radius[o] + a.cth) * a.inv_len));
                 width = -a.radius[o];
-            } else {
-                double sx = 0.0, sy = 0.0, rmax = 0.0;
-                mtot = 0.0;
-                for (uint32_t k = first; k < first + count; ++k) {
-                    const uint32_t o = a.idx[k];
-                    const double2 p = a.pos[o];
-                    const double mk = a.mass[o];
-                    mtot += mk;
-                    sx += p.x * mk;
-                    sy += p.y * mk;
-                    rmax = fmax(rmax, a.radius[o]);
+                if (a.bucket) {
+                    rec.w = 0.f;  // see multi_body_record; the target's own leaf (distance 0) is
+                    width = 0.0;  // "opened" and has no children
                 }
-                cx = sx / mtot;
-                cy = sy / mtot;
-                rec = make_float4((float)(cx * a.inv_len), (float)(cy * a.inv_len), (float)(mtot * a.inv_mass),
-                                  -(float)((rmax + a.cth) * a.inv_len));
-                width = -rmax;
-            }
-            if (a.bucket) {
-                // a cell of zero width: accepted from any distance > 0, then subject to the cell
-                // rule 2 r_i + collision_th (ComputeForce, barnesHut_kernel.cu:387-399); the target's
-                // own one-body leaf (distance 0) is "opened" and has no children
-                rec.w = 0.f;
-                width = 0.0;
+            } else {
+                const double2 *ls = (const double2 *)a.leaf_sum + 2 * (size_t)first;
+                const double2 sxy = ls[0], smr = ls[1];
+                mtot = smr.x;
+                multi_body_record(a, sxy.x, sxy.y, mtot, smr.y, width0, cx, cy, rec, width, prune);
             }
         } else {
             // updateCenterMass: total = sum of child masses, com = sum(child com * child mass) / total,
@@ -794,23 +974,9 @@ __device__ __forceinline__ void com_level(const ComArgs &a, int d)
             }
             cx = sx / mtot;
             cy = sy / mtot;
-            const int lvl = (int)(meta.w >> 8);
-            width = ldexp(width0, -lvl);
-            const double wt = width * a.inv_len / a.theta;  // width / dist < theta  <=>  dist > width / theta
-            rec = make_float4((float)(cx * a.inv_len), (float)(cy * a.inv_len), (float)(mtot * a.inv_mass),
-                              (float)(wt * wt));
-            // Prune threshold: the cell's centre of mass lies inside the cell, so every point of
-            // the cell is within dist(com) + diagonal of a target.  If that is below collision_th
-            // (less a margin for float rounding) nothing in the cell can contribute.
-            const double height = ldexp(a.box[1] - a.box[3], -lvl);
-            const double reach = a.cth * (1.0 - 1.0e-4) - sqrt(width * width + height * height);
-            prune = reach > 0.0 ? (float)((reach * a.inv_len) * (reach * a.inv_len)) : -1.f;
+            cell_record(a, cx, cy, mtot, (int)(meta.w >> 8), width0, rec, width, prune);
         }
-        double2 *o = (double2 *)a.node_com + 2 * (size_t)u;
-        o[0] = make_double2(cx, cy);
-        o[1] = make_double2(mtot, width);
-        a.node_rec[u] = rec;
-        a.node_aux[u] = make_uint2((meta.z << 3) | nchild, __float_as_uint(prune));
+        store_node(a, u, meta, cx, cy, mtot, width, rec, prune);
     }
 }
 
@@ -848,8 +1014,12 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.inv_len = 1.0 / a.units.len_unit;
     c.inv_mass = 1.0 / a.units.mass_unit;
     c.theta = a.theta;
+    c.cut = b.cut;
+    c.leaf_sum = b.leaf_sum;
     c.cth = a.collision_th;
     c.bucket = a.bucket_depth > 0 ? 1 : 0;
+    hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[b.sorted], b.idx[b.sorted], a.n, a.pos,
+                       a.mass, a.radius, b.leaf_sum);
     // levels beyond the ones the build launched per-level kernels for: one block, one launch
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
@@ -1403,6 +1573,8 @@ int bh_alloc(BhBuffers &b, int n)
     b.node_cap = 2 * (size_t)n + 8;
     b.sort_blocks = (n + SORT_TILE - 1) / SORT_TILE;
     NB_TRY(dev_alloc(b.box, 4));
+    NB_TRY(dev_alloc(b.cut, 2));
+    NB_TRY(dev_alloc(b.leaf_sum, 4 * (size_t)n));
     NB_TRY(dev_alloc(b.bbox_part, 4 * BBOX_BLOCKS));
     for (int k = 0; k < 2; ++k) {
         NB_TRY(dev_alloc(b.keys[k], (size_t)n));
@@ -1435,6 +1607,8 @@ int bh_alloc(BhBuffers &b, int n)
 void bh_free(BhBuffers &b)
 {
     (void)hipFree(b.box);
+    (void)hipFree(b.cut);
+    (void)hipFree(b.leaf_sum);
     (void)hipFree(b.bbox_part);
     for (int k = 0; k < 2; ++k) {
         (void)hipFree(b.keys[k]);

@@ -43,6 +43,14 @@ def tree_arrays(nb, sim):
     return ls, rng, ch, com
 
 
+def cut_keys(nb, sim, ref_keys):
+    """The reference path of every body, cut at the level the library's keys stop at (cells of
+    that level are never opened, so what lies below them is not sorted or built)."""
+    closed, levels = (int(v) for v in sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2))
+    assert levels == min(closed, 31)
+    return ref_keys & ~np.uint64((1 << (62 - 2 * levels)) - 1), levels
+
+
 @pytest.mark.parametrize("name", ["spiral_n256", "random_n4096", "collision_n4096"])
 def test_bbox_keys_sort_are_bit_exact(nb, oracle, name):
     b = bodies_from_golden(golden(name))
@@ -52,7 +60,8 @@ def test_bbox_keys_sort_are_bit_exact(nb, oracle, name):
     box = sim.debug(nb.DBG_BBOX, np.float64, 4)
     assert np.array_equal(box, oracle.bh_bbox(b))
     keys = sim.debug(nb.DBG_KEYS, np.uint64, len(b))
-    ref_keys = oracle.morton_keys(b, box)
+    ref_keys, levels = cut_keys(nb, sim, oracle.morton_keys(b, box))
+    assert 6 <= levels <= 12  # the reference's constants: cutoff 1e10 in a ~1e12 box, theta 0.5
     assert np.array_equal(keys, ref_keys)
     order = np.argsort(ref_keys, kind="stable")
     assert np.array_equal(sim.debug(nb.DBG_SORTED_IDX, np.uint32, len(b)), order.astype(np.uint32))
@@ -67,7 +76,7 @@ def test_radix_sort_matches_cpu_stable_sort_large(nb, oracle, n):
     b = exchange_bodies(sim, b)
     box = sim.debug(nb.DBG_BBOX, np.float64, 4)
     assert np.array_equal(box, oracle.bh_bbox(b))
-    ref_keys = oracle.morton_keys(b, box)
+    ref_keys, _ = cut_keys(nb, sim, oracle.morton_keys(b, box))
     order = np.argsort(ref_keys, kind="stable")
     assert np.array_equal(sim.debug(nb.DBG_SORTED_IDX, np.uint32, n), order.astype(np.uint32))
     assert np.array_equal(sim.debug(nb.DBG_SORTED_KEYS, np.uint64, n), ref_keys[order])
@@ -102,12 +111,26 @@ def test_tree_invariants_and_centre_of_mass(nb, name):
     assert nnodes == ls.max() and nnodes <= 2 * n - 1
     assert rng[0, 0] == 0 and rng[0, 1] == n
     leaves = ch[:, 1] == 0
-    # every body is in exactly one leaf; leaves hold one body (distinct positions)
-    assert leaves.sum() == n and np.all(rng[leaves, 1] == 1)
-    assert np.array_equal(np.sort(rng[leaves, 0]), np.arange(n))
+    closed, levels = (int(v) for v in sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2))
     m = b["mass"][idx]
     p = b["pos"][idx]
     width0 = box[2] - box[0]
+    # every body is in exactly one leaf; a leaf holds one body, or the bodies of one cell of the
+    # level below which no cell is ever opened (then it carries that cell's width and their
+    # centre of mass)
+    assert rng[leaves, 1].sum() == n
+    covered = np.zeros(n, dtype=int)
+    for u in np.flatnonzero(leaves):
+        covered[rng[u, 0]:rng[u, 0] + rng[u, 1]] += 1
+        if rng[u, 1] > 1:
+            first, count = rng[u]
+            assert closed <= 31 and com[u, 3] == width0 / 2.0 ** closed
+            assert len(np.unique(keys[first:first + count])) == 1
+            mm = m[first:first + count]
+            assert com[u, 0] == pytest.approx((mm * p[first:first + count, 0]).sum() / mm.sum(), rel=1e-9, abs=1e-3)
+    assert np.all(covered == 1)
+    if name == "collision_n4096":
+        assert np.any(rng[leaves, 1] > 1)  # two discs of 2048 bodies: some share a level-9 cell
     for u in range(nnodes):
         first, count = rng[u]
         cf, nc = ch[u]
@@ -303,24 +326,31 @@ def test_two_rank_partition_equals_single_rank(nb, oracle):
 
 def test_tree_deeper_than_the_previous_steps(nb, oracle):
     """The per-level build kernels are launched for as many levels as earlier trees had; a tree
-    that suddenly needs many more levels (here: a tight clump replaces a spread-out disc) must
-    still be built completely and give the reference's accelerations."""
-    n = 3000
+    that suddenly needs more levels (here: bodies on a coarse grid, then a sequence converging on
+    a point) must still be built completely and give the reference's accelerations."""
+    n = 65
     wide = oracle.scenario(0, n, 12)
+    g = np.arange(n - 1)
+    wide["pos"][:-1, 0] = -4.0e11 + (g % 8) * 1.1e11 + 1.0e9 * np.sin(g)       # 8 x 8 grid, jittered
+    wide["pos"][:-1, 1] = -4.0e11 + (g // 8) * 1.1e11 + 1.0e9 * np.cos(3 * g)
     with nb.NBodySim(n, nb.BARNES_HUT) as sim:
         sim.set_bodies(wide)
         sim.set_stage_timing(True)
         sim.update(3)
         shallow = int(sim.debug(nb.DBG_COUNTERS, np.uint64, 8)[3])
+        wide = sim.read_bodies()
         tight = wide.copy()
         # a geometric sequence of bodies converging on a point: every cell level splits one body
-        # off, a caterpillar ~26 levels deep (a clump would only add a collapsed chain)
+        # off (a clump would only add a collapsed chain), down to the level below which cells are
+        # never opened and the tree is not built
         k = np.arange(26)
-        tight["pos"][:26] = np.array([3.3e11, -2.1e11]) + 1.0e11 * 0.5 ** k[:, None] * np.array([1.0, 0.7])
+        box = sim.debug(nb.DBG_BBOX, np.float64, 4)
+        corner = np.array([box[0] + 1.0e10, box[1] - 1.0e10])
+        tight["pos"][30:56] = corner + (box[2] - box[0]) * 0.5 ** (k[:, None] + 1) * np.array([1.0, -1.0])
         sim.set_bodies(tight)
         acc = sim.compute_accel()
         deep = int(sim.debug(nb.DBG_COUNTERS, np.uint64, 8)[3])
-        assert deep >= shallow + 8
+        assert deep >= shallow + 4
         ref = oracle.bh_accel(tight)
         dyn = tight["is_dynamic"] != 0
         assert rel_err(acc[dyn], ref[dyn]).max() <= ACC_EXPECTED
