@@ -1032,10 +1032,10 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 // ------------------------------------------------------------------ 6 traversal + integration
 
 #ifndef NB_TR_STACK
-#define NB_TR_STACK 278
+#define NB_TR_STACK 310
 #endif
 #ifndef NB_TR_BATCH
-#define NB_TR_BATCH 48
+#define NB_TR_BATCH 36
 #endif
 constexpr int TR_BATCH = NB_TR_BATCH;     // nodes popped and visited together (at most one per lane)
 constexpr int TR_STACK = NB_TR_STACK;     // entries per wave
