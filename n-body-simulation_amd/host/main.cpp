@@ -9,10 +9,13 @@
 // BarnesHut unless --alg direct is given.  Exactly three positional arguments, or none for
 // the defaults (N 300, Sim 0, Iter 300), as in the reference; bad values print the reference's
 // message and return -1.  Additive flags: --alg bh|direct, --seed S, --theta T, --dump FILE,
-// --dump-every K, --iters K (nBodyCPU form), --integrator euler|leapfrog, --energy (prints the
-// conserved quantities before and after the run), --quiet.
+// --dump-every K, --ppm PREFIX (one image PREFIX_<step>.ppm per dumped step, drawn by the rule
+// of the reference's storeFrame), --window W, --iters K (nBodyCPU form),
+// --integrator euler|leapfrog, --energy (prints the conserved quantities before and after the
+// run), --quiet.
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -39,6 +42,39 @@ void dump_frame(std::FILE *f, const nb_body *b, int n, int step)
         rec[5 * (size_t)i + 4] = b[i].mass;
     }
     std::fwrite(rec.data(), sizeof(double), rec.size(), f);
+}
+
+// One frame as the reference draws it (storeFrame / scaleToWindow, src/gpu/BH/main.cu:28-60):
+// pixel = position * W / NBODY_WIDTH + W / 2 (y not flipped), bodies of mass >= 1.6e29 (HBL) as
+// red discs of radius 5, the others as white discs of radius 1, on black; later bodies overdraw
+// earlier ones.  Written as a binary PPM instead of a video frame.
+void write_ppm(const std::string &path, const nb_body *b, int n, int window)
+{
+    const double scale = (double)window / 10.0e11;  // WINDOW / NBODY_WIDTH (constants.h:21-22,31-32)
+    std::vector<unsigned char> img((size_t)window * window * 3, 0);
+    for (int i = 0; i < n; ++i) {
+        const bool star = b[i].mass >= 1.6e29;
+        const int r = star ? 5 : 1;
+        const int cx = (int)(b[i].position.x * scale + window / 2), cy = (int)(b[i].position.y * scale + window / 2);
+        for (int dy = -r; dy <= r; ++dy)
+            for (int dx = -r; dx <= r; ++dx) {
+                const int x = cx + dx, y = cy + dy;
+                if (dx * dx + dy * dy > r * r || x < 0 || y < 0 || x >= window || y >= window)
+                    continue;
+                unsigned char *px = &img[((size_t)y * window + x) * 3];
+                px[0] = 255;
+                px[1] = star ? 0 : 255;
+                px[2] = star ? 0 : 255;
+            }
+    }
+    std::FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) {
+        std::cerr << "cannot open " << path << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+    std::fprintf(f, "P6\n%d %d\n255\n", window, window);
+    std::fwrite(img.data(), 1, img.size(), f);
+    std::fclose(f);
 }
 
 // checkArgs, src/gpu/BH/main.cu:62-84
@@ -72,8 +108,8 @@ int main(int argc, char **argv)
     int alg = mode == DS ? NB_ALG_DIRECT : NB_ALG_BARNES_HUT;
     unsigned seed = 12345;
     double theta = -1;
-    std::string dump;
-    int dump_every = 1, iters_flag = 300;
+    std::string dump, ppm;
+    int dump_every = 1, iters_flag = 300, window = 2048;
     bool quiet = false, energy = false;
     int integrator = NB_INT_EULER;
     std::vector<const char *> pos;
@@ -95,6 +131,10 @@ int main(int argc, char **argv)
             theta = std::atof(next("--theta"));
         else if (a == "--dump")
             dump = next("--dump");
+        else if (a == "--ppm")
+            ppm = next("--ppm");
+        else if (a == "--window")
+            window = std::atoi(next("--window"));
         else if (a == "--dump-every")
             dump_every = std::atoi(next("--dump-every"));
         else if (a == "--iters")
@@ -161,9 +201,15 @@ int main(int argc, char **argv)
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < iters; ++i) {
         nb.update();
-        if (f && ((i + 1) % dump_every == 0 || i + 1 == iters)) {
+        if ((f || !ppm.empty()) && ((i + 1) % dump_every == 0 || i + 1 == iters)) {
             nb.readDeviceBodies();
-            dump_frame(f, nb.getBodies(), nBodies, i + 1);
+            if (f)
+                dump_frame(f, nb.getBodies(), nBodies, i + 1);
+            if (!ppm.empty()) {
+                char name[32];
+                std::snprintf(name, sizeof(name), "_%06d.ppm", i + 1);
+                write_ppm(ppm + name, nb.getBodies(), nBodies, window < 16 ? 16 : window);
+            }
         }
     }
     nb.sync();

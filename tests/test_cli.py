@@ -81,3 +81,36 @@ def test_cpu_program_argument_order(nb, tmp_path):
     with nb.NBody(200, nb.BARNES_HUT, 1, seed=9) as s:
         s.update(2)
         assert np.array_equal(frames[-1][1][:, 0:2], s.read_bodies()["pos"])
+
+
+@pytest.mark.gpu
+def test_ppm_frames_follow_the_reference_drawing_rule(nb, tmp_path):
+    """storeFrame (src/gpu/BH/main.cu:36-60): pixel = pos * W / 1e12 + W / 2, suns (mass >= 1.6e29) red
+    radius 5, planets white radius 1, black background."""
+    n, w = 300, 256
+    prefix = tmp_path / "frame"
+    r = subprocess.run([binary("BarnesHut"), str(n), "2", "2", "--seed", "5", "--ppm", str(prefix), "--dump-every", "2",
+                        "--window", str(w), "--energy"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "start: E=" in r.stdout and "end: E=" in r.stdout
+    raw = (tmp_path / "frame_000002.ppm").read_bytes()
+    header = b"P6\n%d %d\n255\n" % (w, w)
+    assert raw.startswith(header)
+    img = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(w, w, 3)
+    with nb.NBodySim(n, nb.BARNES_HUT) as sim:
+        sim.setup(nb.COLLISION, 5)
+        sim.update(2)
+        b = sim.read_bodies()
+    px = (b["pos"] * (w / 10.0e11) + w // 2).astype(int)
+    suns = b["mass"] >= 1.6e29
+    assert suns.sum() == 2
+    for x, y in px[suns]:
+        assert tuple(img[y, x]) == (255, 0, 0) and tuple(img[y + 5, x]) == (255, 0, 0)
+    red = (img[..., 0] == 255) & (img[..., 1] == 0)
+    white = img.min(axis=2) == 255
+    assert 2 * 60 <= red.sum() <= 2 * 81  # two discs of radius 5
+    assert white.sum() > 100 and np.all(red | white | (img.max(axis=2) == 0))
+    inside = np.all((px >= 0) & (px < w), axis=1) & ~suns
+    far_from_sun = inside & np.all(np.abs(px[:, None, :] - px[suns][None, :, :]).max(axis=2) > 6, axis=1)
+    for x, y in px[far_from_sun][:50]:
+        assert tuple(img[y, x]) == (255, 255, 255)
