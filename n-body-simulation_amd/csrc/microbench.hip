@@ -311,6 +311,53 @@ __global__ void k_ldsw(float *out, float b, float c)
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// ---- all-pairs inner loop with the squared distances from the matrix cores ----
+// 32 targets x 32 sources per step: r^2 = |a|^2 + |b|^2 - 2 a.b as a rank-4 product on
+// v_mfma_f32_32x32x2_f32 (two issues), then per pair rsq, cube and three accumulations on the
+// vector ALU: 7 vector issue slots per pair instead of 10.
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_pairs_mfma(float *out, float b, float c)
+{
+    __shared__ float4 tile[1024];
+    for (int k = threadIdx.x; k < 1024; k += 256)
+        tile[k] = make_float4(b * (float)(k % 37) + 3.f, c * (float)(k % 41) + 5.f, 1.f, 0.f);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const bool hi = lane >= 32;
+    const float ax = 0.01f * (lane & 31), ay = 0.02f * (lane & 31);
+    const float A1 = hi ? 1.f : ax * ax + ay * ay, A2 = hi ? -2.f * ay : -2.f * ax;
+    float S[16], FX[16], FY[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        S[r] = FX[r] = FY[r] = 0.f;
+    for (int it = 0; it < ITERS / 8; ++it) {
+#pragma unroll 2
+        for (int t = 0; t < 32; ++t) {
+            const float4 src = tile[t * 32 + (lane & 31)];
+            const float bx = src.x - 1.5f, by = src.y - 2.5f;
+            const float n2 = __builtin_fmaf(by, by, __builtin_fmaf(bx, bx, 1e-9f));
+            const float B1 = hi ? n2 : 1.f, B2 = hi ? by : bx;
+            f16v d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2, d, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float rinv = __builtin_amdgcn_rsqf(d[r]);
+                const float sc = (rinv * rinv) * rinv;
+                S[r] += sc;
+                FX[r] = __builtin_fmaf(sc, bx, FX[r]);
+                FY[r] = __builtin_fmaf(sc, by, FY[r]);
+            }
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        acc += S[r] + FX[r] + FY[r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 template <typename K>
 static double run(K kernel, int blocks, float *out, int reps)
 {
@@ -367,6 +414,11 @@ int main()
             for (auto &r : rows)
                 printf("  %s %.2f", r.name, r.t * clk / (ITERS * r.per_iter * wps));
             printf("\n");
+        }
+        {
+            const double tm = run(k_pairs_mfma, blocks, out, reps);
+            printf("waves/SIMD %d: pairs with MFMA distances: %.2f T pairs/s\n", wps,
+                   (double)blocks * 4 * (ITERS / 8) * 32 * 1024 / tm / 1e12);
         }
         printf("waves/SIMD %d: fma %.2f Tlane-op/s (%.1f TFLOP/s, %.1f lane-op/clk/CU) | pk_fma %.2f Tfma/s (%.1f TFLOP/s) | "
                "rsq %.2f T/s | mix(2rsq+6fma) %.2f Tinst/s | cmp+cndmask %.2f Tinst/s\n",
