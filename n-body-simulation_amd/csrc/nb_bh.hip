@@ -440,19 +440,6 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
     }
 }
 
-__global__ __launch_bounds__(256) void k_gather_sorted(const uint32_t *idx, int n, const double2 *pos,
-                                                       const double *mass, const double *radius, double inv_len,
-                                                       double inv_mass, float4 *posm_s)
-{
-    int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n)
-        return;
-    const uint32_t o = idx[k];
-    const double2 p = pos[o];
-    posm_s[k] = make_float4((float)(p.x * inv_len), (float)(p.y * inv_len), (float)(mass[o] * inv_mass),
-                            (float)(radius[o] * inv_len));
-}
-
 int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     const int n = a.n;
@@ -467,8 +454,6 @@ int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     static_assert(SORT_PASSES % 2 == 0, "the last pass must write buffer 0");
     const int cur = 0;
     b.sorted = cur;
-    hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, s, b.idx[cur], n, a.pos, a.mass, a.radius,
-                       1.0 / a.units.len_unit, 1.0 / a.units.mass_unit, b.posm_s);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -837,8 +822,11 @@ __device__ __forceinline__ void store_node(const ComArgs &a, uint32_t u, const u
 // chunk; a run that goes on past the chunk is finished by the same wave, 64 bodies at a time
 // (the waves of the chunks it crosses skip those bodies).  The order of the additions is fixed
 // by the positions alone, so the sums are reproducible.
+// The same pass writes every body's float record {x, y, m, radius} in sorted order (the
+// traversal's targets and the one-body leaves), since it reads exactly what that needs.
 __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const uint32_t *idx, int n, const double2 *pos,
-                                                   const double *mass, const double *radius, double *leaf_sum)
+                                                   const double *mass, const double *radius, double inv_len,
+                                                   double inv_mass, float4 *posm_s, double *leaf_sum)
 {
     const int lane = lane_id();
     const int chunk = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
@@ -856,6 +844,7 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
         sx = p.x * sm;
         sy = p.y * sm;
         rm = radius[o];
+        posm_s[k] = make_float4((float)(p.x * inv_len), (float)(p.y * inv_len), (float)(sm * inv_mass), (float)(rm * inv_len));
     }
     const uint64_t heads = __builtin_amdgcn_ballot_w64(valid && (k == 0 || key != prev));
     // first lane of this lane's run, if the run starts in this chunk
@@ -1019,7 +1008,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.cth = a.collision_th;
     c.bucket = a.bucket_depth > 0 ? 1 : 0;
     hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[b.sorted], b.idx[b.sorted], a.n, a.pos,
-                       a.mass, a.radius, b.leaf_sum);
+                       a.mass, a.radius, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum);
     // levels beyond the ones the build launched per-level kernels for: one block, one launch
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
