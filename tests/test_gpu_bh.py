@@ -358,3 +358,40 @@ def test_tree_deeper_than_the_previous_steps(nb, oracle):
         sim.set_bodies(wide)
         acc = sim.compute_accel()
         assert rel_err(acc[dyn], oracle.bh_accel(wide)[dyn]).max() <= ACC_EXPECTED
+
+
+@pytest.mark.parametrize("case", ["tiny_system", "wide_and_clump", "theta_small", "theta_large", "no_cutoff", "huge_cutoff"])
+def test_closed_level_edge_cases(nb, oracle, case):
+    """The level below which the tree is not built depends on box, cutoff and theta; whatever it
+    comes out as (none, the root itself, anything between), the accelerations are the full tree's."""
+    n = 600
+    b = oracle.scenario(0, n, 77)
+    kw = {}
+    if case == "tiny_system":
+        b["pos"] *= 1.0e-3  # everything within a few 1e8 m: all inside each other's cutoff
+        kw = dict(bbox_margin=1.0e6)
+    elif case == "wide_and_clump":
+        b["pos"][:300] = b["pos"][0] + 1.0e-4 * (b["pos"][:300] - b["pos"][0])  # half the bodies in one small cell
+    elif case == "theta_small":
+        kw = dict(theta=0.05)
+    elif case == "theta_large":
+        kw = dict(theta=1.5)
+    elif case == "no_cutoff":
+        kw = dict(collision_th=0.0)
+    elif case == "huge_cutoff":
+        kw = dict(collision_th=3.0e11)
+    with nb.NBodySim(n, nb.BARNES_HUT, nb.default_params(**kw)) as sim:
+        sim.set_bodies(b)
+        acc = sim.compute_accel()
+        closed, levels = (int(v) for v in sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2))
+    ref = oracle.bh_accel(b, oracle.params(**kw))
+    dyn = b["is_dynamic"] != 0
+    if case == "no_cutoff":
+        assert closed == 32 and levels == 31
+        tol = 1.0e-4  # float coordinates resolve 6e4 m of a 1e12 m box; the cutoff is what keeps pairs apart
+    else:
+        tol = ACC_EXPECTED
+    if case in ("tiny_system", "huge_cutoff"):
+        assert closed <= (2 if case == "tiny_system" else 4)
+    scale = np.abs(ref[dyn]).max()
+    assert np.all(np.abs(acc[dyn] - ref[dyn]) <= tol * np.maximum(np.linalg.norm(ref[dyn], axis=1, keepdims=True), 1e-12 * scale) + 1e-30)
