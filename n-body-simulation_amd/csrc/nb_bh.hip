@@ -254,16 +254,23 @@ constexpr int SORT_BINS = 1 << SORT_BITS;
 constexpr int KEY_BITS = 2 * BH_KEY_LEVELS;
 constexpr int SORT_PASSES = (KEY_BITS + SORT_BITS - 1) / SORT_BITS;
 
-// Keys computed to `key_levels` digits are zero in their low KEY_BITS - 2 key_levels bits; a
-// sort pass whose digit lies wholly in there would move nothing and returns at once.  Pass p
-// reads buffer p & 1 and writes the other, so the last pass always leaves the result in
-// buffer 0 and the keys are written where the first pass with work reads them: the host
-// launches the same kernels every step and never needs to know how many did anything.
+// The 62 key bits are sorted as the top of a 64-bit word (key << 2), eight bits a pass, so that the
+// passes line up with the TOP of the key: keys computed to `key_levels` digits are zero in the low
+// 64 - 2 key_levels bits of that word, and a pass whose digit lies wholly in there would move
+// nothing and returns at once (8 levels -> two passes with work, 9..12 -> three).  Pass p reads
+// buffer p & 1 and writes the other, so the last pass always leaves the result in buffer 0 and
+// the keys are written where the first pass with work reads them: the host launches the same
+// kernels every step and never needs to know how many did anything.
 __device__ __forceinline__ int first_sort_pass(uint32_t key_levels)
 {
-    const int zero_bits = KEY_BITS - 2 * (int)key_levels;
+    const int zero_bits = 64 - 2 * (int)key_levels;
     const int p = zero_bits / SORT_BITS;
     return p < SORT_PASSES - 1 ? p : SORT_PASSES - 1;
+}
+
+__device__ __forceinline__ uint32_t sort_digit(uint64_t key, int pass)
+{
+    return (uint32_t)((key << 2) >> (pass * SORT_BITS)) & (SORT_BINS - 1);
 }
 
 __global__ __launch_bounds__(256) void k_sort_count(const uint64_t *keys, int n, int pass, const uint32_t *cut,
@@ -271,7 +278,6 @@ __global__ __launch_bounds__(256) void k_sort_count(const uint64_t *keys, int n,
 {
     if (pass < first_sort_pass(cut[1]))
         return;
-    const int shift = pass * SORT_BITS;
     __shared__ uint32_t h[SORT_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256) void k_sort_count(const uint64_t *keys, int n,
     for (int it = 0; it < SORT_ITEMS; ++it) {
         int i = base + it * 256 + threadIdx.x;
         if (i < n)
-            atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (SORT_BINS - 1)], 1u);
+            atomicAdd(&h[sort_digit(keys[i], pass)], 1u);
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
@@ -354,7 +360,6 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
 {
     if (pass < first_sort_pass(cut[1]))
         return;
-    const int shift = pass * SORT_BITS;
     __shared__ uint32_t wcnt[4][SORT_BINS];
     __shared__ uint32_t dbase[SORT_BINS];
     __shared__ uint32_t lstart[SORT_BINS];
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
         const bool valid = i < n;
         key[it] = valid ? keys_in[i] : ~0ull;
         val[it] = valid ? idx_in[i] : 0u;
-        const uint32_t d = (uint32_t)(key[it] >> shift) & (SORT_BINS - 1);
+        const uint32_t d = sort_digit(key[it], pass);
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int bit = 0; bit < SORT_BITS; ++bit) {
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const int i = chunk + it * 64 + lane;
         if (i < n) {
-            const uint32_t d = (uint32_t)(key[it] >> shift) & (SORT_BINS - 1);
+            const uint32_t d = sort_digit(key[it], pass);
             const uint32_t p = lstart[d] + wcnt[w][d] + rank[it];
             lkey[p] = key[it];
             lval[p] = val[it];
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
     const int count = n - first < SORT_TILE ? n - first : SORT_TILE;
     for (int t = tid; t < count; t += 256) {
         const uint64_t k = lkey[t];
-        const uint32_t d = (uint32_t)(k >> shift) & (SORT_BINS - 1);
+        const uint32_t d = sort_digit(k, pass);
         const uint32_t dst = dbase[d] + (uint32_t)t;
         keys_out[dst] = k;
         idx_out[dst] = lval[t];
