@@ -191,6 +191,15 @@ int nb_debug_read(nb_sim *sim, int which, void *out, size_t bytes, size_t *writt
 int nb_set_stage_timing(nb_sim *sim, int on);
 int nb_stage_ms(nb_sim *sim, float *out, int count);
 
+/* Re-derives the exchange order (see NB_DBG_ORDER) from the current positions and re-sorts the
+ * device state by it, through the host.  Nothing the caller sees changes (nb_read_bodies keeps
+ * returning bodies in the caller's order; results differ only by the rounding of a different
+ * summation order); it restores the speed of long direct-sum runs, whose kernel relies on
+ * neighbouring indices being neighbours in space.  nb_step does it by itself for the direct sum
+ * every max(64, min(4096, 5e7 / n)) steps.  Not for partitioned simulations.  The reference keeps
+ * bodies in creation order and has nothing of the kind. */
+int nb_refresh_order(nb_sim *sim);
+
 /* Conserved quantities of the current state, computed in FP64 (not part of the hot path):
  * out[0] total mass, [1..2] centre of mass, [3..4] momentum, [5] angular momentum about the
  * origin, [6] kinetic energy, [7] potential energy -G sum_{i<j} m_i m_j / sqrt(d^2 + eps^2) over

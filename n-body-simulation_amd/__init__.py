@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "nb_default_params", "nb_init_scenario", "nb_create", "nb_destroy", "nb_setup", "nb_set_bodies",
     "nb_step", "nb_compute_accel", "nb_read_bodies", "nb_sync", "nb_set_stream", "nb_set_partition",
     "nb_exchange_buffer", "nb_step_local", "nb_step_finish", "nb_debug_read", "nb_set_stage_timing",
-    "nb_stage_ms", "nb_diagnostics", "nb_last_error", "nb_version",
+    "nb_stage_ms", "nb_diagnostics", "nb_refresh_order", "nb_last_error", "nb_version",
 ]
 
 
@@ -104,6 +104,7 @@ def load_library(path=None):
     lib.nb_set_stage_timing.argtypes = [vp, i]
     lib.nb_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]
     lib.nb_diagnostics.argtypes = [vp, C.POINTER(C.c_double), i]
+    lib.nb_refresh_order.argtypes = [vp]
     lib.nb_last_error.restype = C.c_char_p
     lib.nb_version.restype = C.c_char_p
     for name in ABI_SYMBOLS:
@@ -207,6 +208,10 @@ class NBodySim:
         _check(self._lib.nb_stage_ms(self._h, out, 8))
         names = ["bbox", "keys", "sort", "build", "com", "force", "other"]
         return {k: out[i] for i, k in enumerate(names)}
+
+    def refresh_order(self):
+        """Re-sorts the device state by the bodies' current positions (see nb_refresh_order)."""
+        _check(self._lib.nb_refresh_order(self._h))
 
     def diagnostics(self):
         """Conserved quantities of the current state (FP64); potential is NaN above 131072 bodies."""

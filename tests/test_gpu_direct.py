@@ -231,3 +231,49 @@ def test_call_order_errors(nb):
         sim.set_partition(0, 2)
         with pytest.raises(nb.NBodyError, match="partitioned"):
             sim.update()
+
+
+@pytest.mark.parametrize("alg", ["direct", "bh"])
+def test_refresh_order_changes_nothing_the_caller_sees(nb, alg):
+    """nb_refresh_order re-sorts the device state by the current positions; the run goes on as
+    before up to the rounding of a different summation order."""
+    b0 = bodies_from_golden(golden("spiral_n4096"))
+    a = nb.NBodySim(len(b0), nb.DIRECT if alg == "direct" else nb.BARNES_HUT)
+    a.set_bodies(b0)
+    a.update(40)
+    ra = a.read_bodies()
+    a.close()
+    c = nb.NBodySim(len(b0), nb.DIRECT if alg == "direct" else nb.BARNES_HUT)
+    c.set_bodies(b0)
+    c.update(20)
+    before = c.order().copy()
+    mid = c.read_bodies()
+    c.refresh_order()
+    after = c.order()
+    assert np.array_equal(np.sort(after), np.arange(len(b0))) and not np.array_equal(before, after)
+    again = c.read_bodies()
+    for f in ("pos", "vel", "acc", "mass", "radius", "is_dynamic"):
+        assert np.array_equal(mid[f], again[f])
+    c.update(20)
+    rc = c.read_bodies()
+    c.close()
+    # FP32 partial sums in another order: accelerations differ by ~1e-7 relative, which 20 steps
+    # of dt = 25000 s turn into ~1e-8 of the system's extent for the innermost bodies
+    scale = np.abs(ra["pos"]).max()
+    assert np.abs(ra["pos"] - rc["pos"]).max() / scale < 1e-7
+    assert np.abs(ra["vel"] - rc["vel"]).max() / np.abs(ra["vel"]).max() < 1e-5
+
+
+def test_long_direct_run_refreshes_by_itself(nb, oracle):
+    """n = 800000 bodies would refresh every 64 steps; here the interval is 4096, so force it
+    through a small n with many steps instead: 4200 steps of 64 bodies stay on the oracle's path."""
+    b0 = oracle.scenario(0, 64, 3)
+    sim = nb.NBodySim(64, nb.DIRECT)
+    sim.set_bodies(b0)
+    first = sim.order().copy()
+    sim.update(4200)
+    got = sim.read_bodies()
+    assert not np.array_equal(first, sim.order())  # bodies have orbited: the order was renewed
+    sim.close()
+    want = oracle.direct_step(b0, 4200)
+    assert np.abs(got["pos"] - want["pos"]).max() / np.abs(want["pos"]).max() < 1e-4
