@@ -852,6 +852,8 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
         posm_s[k] = make_float4((float)(p.x * inv_len), (float)(p.y * inv_len), (float)(sm * inv_mass), (float)(rm * inv_len));
     }
     const uint64_t heads = __builtin_amdgcn_ballot_w64(valid && (k == 0 || key != prev));
+    if (heads == 0ull)
+        return;  // the whole chunk lies inside a run that started earlier: that run's wave sums it
     // first lane of this lane's run, if the run starts in this chunk
     const uint64_t upto = heads & ((2ull << lane) - 1ull);
     const int start = upto ? 63 - __builtin_clzll(upto) : -1;
@@ -882,39 +884,38 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
     }
     const int start63 = __shfl(start, 63);
     if (goes_on && start63 >= 0) {
-        double am = __shfl(sm, 63), ax = __shfl(sx, 63), ay = __shfl(sy, 63), ar = __shfl(rm, 63);
+        // every lane adds up the bodies it meets (position tail + lane, + 64, ...) until the
+        // run ends; one fold across the wave at the end
+        double pm = 0.0, px = 0.0, py = 0.0, pr = 0.0;
         for (int base = tail; base < n; base += 64) {
             const int kk = base + lane;
             const bool in = kk < n && keys[kk] == last_key;
-            double pm = 0.0, px = 0.0, py = 0.0, pr = 0.0;
             if (in) {
                 const uint32_t o = idx[kk];
                 const double2 p = pos[o];
-                pm = mass[o];
-                px = p.x * pm;
-                py = p.y * pm;
-                pr = radius[o];
+                const double m = mass[o];
+                pm += m;
+                px += p.x * m;
+                py += p.y * m;
+                pr = fmax(pr, radius[o]);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                pm += __shfl_xor(pm, o);
-                px += __shfl_xor(px, o);
-                py += __shfl_xor(py, o);
-                pr = fmax(pr, __shfl_xor(pr, o));
-            }
-            am += pm;
-            ax += px;
-            ay += py;
-            ar = fmax(ar, pr);
             if (__builtin_amdgcn_ballot_w64(in) != ~0ull)
                 break;  // the run ended inside these 64
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            pm += __shfl_xor(pm, o);
+            px += __shfl_xor(px, o);
+            py += __shfl_xor(py, o);
+            pr = fmax(pr, __shfl_xor(pr, o));
+        }
+        const double hx = __shfl(sx, 63), hy = __shfl(sy, 63), hm = __shfl(sm, 63), hr = __shfl(rm, 63);
         if (lane == 0) {
             double *o = leaf_sum + 4 * (size_t)(chunk + start63);
-            o[0] = ax;
-            o[1] = ay;
-            o[2] = am;
-            o[3] = ar;
+            o[0] = hx + px;
+            o[1] = hy + py;
+            o[2] = hm + pm;
+            o[3] = fmax(hr, pr);
         }
     }
 }
