@@ -1,4 +1,4 @@
-"""Times the BASELINE.json configurations on one GPU (tuning/record aid, not a test)."""
+"""Times the reference benchmark configurations (N = 65536 direct, 1M and 5M Barnes-Hut, 1M direct, 50M Barnes-Hut) on one GPU (tuning/record aid, not a test)."""
 import os
 import sys
 import time
