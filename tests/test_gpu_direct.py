@@ -277,3 +277,27 @@ def test_long_direct_run_refreshes_by_itself(nb, oracle):
     sim.close()
     want = oracle.direct_step(b0, 4200)
     assert np.abs(got["pos"] - want["pos"]).max() / np.abs(want["pos"]).max() < 1e-4
+
+
+def test_full_size_direct_properties(nb, oracle):
+    """The N = 1,000,000 direct-sum configuration itself: sampled targets against the oracle, and
+    Newton's third law over all bodies (the pair rule is symmetric, so sum m a vanishes up to the
+    float rounding of the pair forces)."""
+    n = 1000000
+    b = nb.init_scenario(nb.SPIRAL, n, 12345)
+    acc = gpu_accel(nb, b, nb.DIRECT)
+    assert np.all(np.isfinite(acc))
+    targets = np.sort(np.random.default_rng(11).choice(n, 64, replace=False)).astype(np.int32)
+    ref = oracle.direct_accel_list(b, targets)
+    err = rel_err(acc[targets], ref)
+    assert err.max() <= ACC_TOL, err.max()
+    dyn = b["is_dynamic"] != 0
+    f = b["mass"][:, None] * acc
+    # the static sun gets no acceleration of its own: leave out the force the others feel from it
+    sun = np.flatnonzero(~dyn)
+    assert len(sun) == 1
+    d = b["pos"][sun[0]] - b["pos"][dyn]
+    r = np.sqrt((d ** 2).sum(1) + 0.25)
+    from_sun = (6.67e-11 * b["mass"][sun[0]] * b["mass"][dyn] / (r ** 3 + 0.25))[:, None] * d
+    net = (f[dyn] - from_sun).sum(0)
+    assert np.abs(net).max() / np.abs(f[dyn] - from_sun).sum() < 1.0e-5
