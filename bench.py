@@ -75,11 +75,10 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-        if stage_timing:
-            for k, v in sim.stage_ms().items():
-                stages[k] = stages.get(k, 0.0) + v / steps
     barrier_sync(world)
     dt = time.perf_counter() - t0
+    if stage_timing:
+        stages = sim.stage_ms()  # HIP events recorded over these steps, read only now: mean per step
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

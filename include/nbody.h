@@ -184,9 +184,11 @@ enum nb_debug_array {
 /* Copies the array into out (bytes = capacity of out); *written gets the size. */
 int nb_debug_read(nb_sim *sim, int which, void *out, size_t bytes, size_t *written);
 
-/* on: bit 0 = time every stage with HIP events on the simulation's stream (nb_step then
- * waits for the stream), bit 1 = collect the NB_DBG_COUNTERS statistics (slower traversal).
- * nb_stage_ms: milliseconds per stage of the last step or nb_compute_accel:
+/* on: bit 0 = time every stage with HIP events on the simulation's stream (recorded without
+ * waiting: the host only waits when 32 steps are pending or nb_stage_ms is called), bit 1 =
+ * collect the NB_DBG_COUNTERS statistics (slower traversal).
+ * nb_stage_ms: mean milliseconds per stage over the steps (or nb_compute_accel calls) since the
+ * previous nb_stage_ms call or since timing was switched on:
  * [0] bbox [1] keys [2] sort [3] build [4] com [5] force+integrate [6] other. */
 int nb_set_stage_timing(nb_sim *sim, int on);
 int nb_stage_ms(nb_sim *sim, float *out, int count);

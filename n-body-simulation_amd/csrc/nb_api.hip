@@ -73,8 +73,11 @@ struct nb_sim {
 
     // stage timing
     int timing = 0;
-    hipEvent_t ev[8] = {};
-    float stage_ms[8] = {};
+    static constexpr int TIMING_RING = 32;  // steps whose events may be pending before the host waits
+    hipEvent_t ev[TIMING_RING][8] = {};
+    int ev_used = 0;          // event sets recorded and not yet read
+    double stage_sum[8] = {};  // milliseconds per stage summed over stage_steps steps
+    int stage_steps = 0;
 };
 
 namespace {
@@ -185,7 +188,7 @@ BhStepArgs bh_args(nb_sim *s, int do_integrate)
 void mark(nb_sim *s, int k)
 {
     if (s->timing)
-        (void)hipEventRecord(s->ev[k], s->stream);
+        (void)hipEventRecord(s->ev[s->ev_used][k], s->stream);
 }
 
 int step_local(nb_sim *s, int do_integrate)
@@ -233,19 +236,32 @@ int step_finish(nb_sim *s)
     return NB_OK;
 }
 
+// Reads the event sets recorded so far into the per-stage sums (waits for the stream).
+int drain_timing(nb_sim *s)
+{
+    if (s->ev_used == 0)
+        return NB_OK;
+    NB_HIP(hipStreamSynchronize(s->stream));
+    const int last = s->alg == NB_ALG_DIRECT ? 1 : 6;
+    for (int e = 0; e < s->ev_used; ++e) {
+        for (int k = 0; k < last; ++k) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s->ev[e][k], s->ev[e][k + 1]) == hipSuccess)
+                s->stage_sum[s->alg == NB_ALG_DIRECT ? 5 : k] += ms;
+        }
+        s->stage_steps += 1;
+    }
+    s->ev_used = 0;
+    return NB_OK;
+}
+
+// A step's events are recorded: nothing is waited for until the ring is full or the caller asks.
 int collect_timing(nb_sim *s)
 {
     if (!s->timing)
         return NB_OK;
-    NB_HIP(hipStreamSynchronize(s->stream));
-    for (int k = 0; k < 8; ++k)
-        s->stage_ms[k] = 0.f;
-    const int last = s->alg == NB_ALG_DIRECT ? 1 : 6;
-    for (int k = 0; k < last; ++k) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s->ev[k], s->ev[k + 1]) == hipSuccess)
-            s->stage_ms[s->alg == NB_ALG_DIRECT ? 5 : k] = ms;
-    }
+    if (++s->ev_used == nb_sim::TIMING_RING)
+        return drain_timing(s);
     return NB_OK;
 }
 
@@ -264,9 +280,10 @@ void release(nb_sim *s)
     (void)hipFree(s->part);
     (void)hipFree(s->ds_meta);
     bh_free(s->bh);
-    for (auto &e : s->ev)
-        if (e)
-            (void)hipEventDestroy(e);
+    for (auto &set : s->ev)
+        for (auto &e : set)
+            if (e)
+                (void)hipEventDestroy(e);
     if (s->own_stream && s->stream)
         (void)hipStreamDestroy(s->stream);
 }
@@ -341,9 +358,10 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
     } else {
         chk(bh_alloc(s->bh, n));
     }
-    for (auto &e : s->ev)
-        if (rc == NB_OK && hipEventCreate(&e) != hipSuccess)
-            chk(fail(NB_ERR_HIP, "hipEventCreate failed"));
+    for (auto &set : s->ev)
+        for (auto &e : set)
+            if (rc == NB_OK && hipEventCreate(&e) != hipSuccess)
+                chk(fail(NB_ERR_HIP, "hipEventCreate failed"));
     if (rc != NB_OK) {
         release(s);
         delete s;
@@ -528,11 +546,10 @@ int nb_step(nb_sim *s, int nsteps)
     for (int k = 0; k < nsteps; ++k) {
         NB_TRY(step_local(s, 1));
         NB_TRY(step_finish(s));
+        NB_TRY(collect_timing(s));
         if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= interval)
             NB_TRY(nb_refresh_order(s));
     }
-    if (nsteps > 0)
-        NB_TRY(collect_timing(s));
     return NB_OK;
 }
 
@@ -674,8 +691,12 @@ int nb_set_stage_timing(nb_sim *s, int on)
 {
     if (!s)
         return fail(NB_ERR_ARG, "nb_set_stage_timing: sim is NULL");
+    NB_TRY(drain_timing(s));
     s->timing = (on & 1) ? 1 : 0;
     s->collect_stats = (on & 2) ? 1 : 0;
+    for (double &v : s->stage_sum)
+        v = 0.0;
+    s->stage_steps = 0;
     return NB_OK;
 }
 
@@ -683,8 +704,12 @@ int nb_stage_ms(nb_sim *s, float *out, int count)
 {
     if (!s || !out)
         return fail(NB_ERR_ARG, "nb_stage_ms: NULL argument");
+    NB_TRY(drain_timing(s));
     for (int k = 0; k < count; ++k)
-        out[k] = k < 8 ? s->stage_ms[k] : 0.f;
+        out[k] = (k < 8 && s->stage_steps > 0) ? (float)(s->stage_sum[k] / s->stage_steps) : 0.f;
+    for (double &v : s->stage_sum)
+        v = 0.0;
+    s->stage_steps = 0;
     return NB_OK;
 }
 
