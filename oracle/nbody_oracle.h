@@ -70,6 +70,38 @@ void orc_bh_gpu_step(const orc_params *p, int n, orc_body *b, int depth, int nst
  * 2*(below the y midpoint) + (right of the x midpoint). */
 void orc_morton_keys(int n, const orc_body *b, const double *box, uint64_t *keys);
 
+/* ---- three dimensions (oracle/nbody_oracle3.c) ----
+ * The reference is two-dimensional throughout; its authors name 3-D and an octree as future
+ * work.  These functions extend its rules by the third coordinate and change nothing else:
+ * distance sqrt(dx^2+dy^2+dz^2), the same softening and cutoff tests, an octree with one body
+ * per leaf whose cells are split at the midpoint of every axis (z like y: mid <= z is the upper
+ * half), children visited in the order of 4*(lower z) + 2*(lower y) + (right x) -- for bodies
+ * that all have z = 0 that is the reference's TL,TR,BL,BR and the octree's cells are the
+ * quadtree's -- and the opening test cell x-width / dist < theta.
+ * Parity pin: with every z = 0 these functions return bit for bit what the 2-D functions above
+ * return (tests/test_oracle_golden.py), and those are pinned by the compiled reference.  For
+ * z != 0 nothing of the reference exists to compare with: parity unpinned. */
+typedef struct orc3_body {
+    uint8_t is_dynamic;
+    uint8_t pad_[7];
+    double mass, radius;
+    double p[3], v[3], a[3];
+} orc3_body;
+
+/* The 2-D scenario `sim` for the same seed, then one more rand() per body in index order:
+ * z = thickness * (2 u - 1), except that bodies of the suns' mass stay at z = 0.  vz = 0. */
+int orc3_init_scenario(int sim, int n, unsigned seed, double thickness, orc3_body *out);
+void orc3_direct_accel(const orc_params *p, int n, const orc3_body *b, int t0, int t1, double *acc);
+void orc3_direct_step(const orc_params *p, int n, orc3_body *b, int nsteps);
+/* box: tl.x, tl.y, br.x, br.y as in orc_bh_bbox, then the upper and the lower z bound. */
+void orc3_bh_bbox(const orc_params *p, int n, const orc3_body *b, double *box);
+/* stats as orc_bh_accel; acc = 3 doubles per body. */
+int orc3_bh_accel(const orc_params *p, int n, const orc3_body *b, double *acc, double *stats);
+int orc3_bh_step(const orc_params *p, int n, orc3_body *b, int nsteps);
+/* Octant path of each body, 20 levels: the digit of level l sits in bits [61-3l, 59-3l] and is
+ * 4*(below the z midpoint) + 2*(below the y midpoint) + (right of the x midpoint). */
+void orc3_morton_keys(int n, const orc3_body *b, const double *box, uint64_t *keys);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,29 @@ BODY_DTYPE = np.dtype(
 )
 
 
+# The 3-D body of the library's nb_body3 / the oracle's orc3_body: 96 bytes.
+BODY3_DTYPE = np.dtype(
+    {
+        "names": ["is_dynamic", "mass", "radius", "pos", "vel", "acc"],
+        "formats": [np.uint8, np.float64, np.float64, (np.float64, 3), (np.float64, 3), (np.float64, 3)],
+        "offsets": [0, 8, 16, 24, 48, 72],
+        "itemsize": 96,
+    }
+)
+
+
+def lift3(b, z=None):
+    """2-D bodies as 3-D bodies in the plane z = 0 (or at the given heights)."""
+    out = np.zeros(len(b), dtype=BODY3_DTYPE)
+    for f in ("is_dynamic", "mass", "radius"):
+        out[f] = b[f]
+    for f in ("pos", "vel", "acc"):
+        out[f][:, :2] = b[f]
+    if z is not None:
+        out["pos"][:, 2] = z
+    return out
+
+
 class Params(C.Structure):
     _fields_ = [
         ("gravity", C.c_double),
@@ -63,6 +86,16 @@ class Oracle:
         L.orc_bh_gpu_bbox.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p]
         L.orc_bh_gpu_accel.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_bh_gpu_step.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc3_init_scenario.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_double, C.c_void_p]
+        L.orc3_init_scenario.restype = C.c_int
+        L.orc3_direct_accel.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc3_direct_step.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int]
+        L.orc3_bh_bbox.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p]
+        L.orc3_bh_accel.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc3_bh_accel.restype = C.c_int
+        L.orc3_bh_step.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int]
+        L.orc3_bh_step.restype = C.c_int
+        L.orc3_morton_keys.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 
     def params(self, **kw):
         p = Params()
@@ -140,6 +173,55 @@ class Oracle:
         b = b.copy()
         self.lib.orc_bh_gpu_step(C.byref(p), len(b), _ptr(b), depth, nsteps)
         return b
+
+    # ---- three dimensions (bodies of BODY3_DTYPE) ----
+
+    def scenario3(self, sim, n, seed=12345, thickness=0.0):
+        m = 5 if sim == 3 else n
+        b = np.zeros(m, dtype=BODY3_DTYPE)
+        if self.lib.orc3_init_scenario(sim, m, seed, thickness, _ptr(b)) != 0:
+            raise ValueError("orc3_init_scenario failed")
+        return b
+
+    def direct_accel3(self, b, p=None, t0=0, t1=None):
+        p = p or self.params()
+        t1 = len(b) if t1 is None else t1
+        acc = np.zeros((t1 - t0, 3))
+        self.lib.orc3_direct_accel(C.byref(p), len(b), _ptr(b), t0, t1, _ptr(acc))
+        return acc
+
+    def direct_step3(self, b, nsteps, p=None):
+        p = p or self.params()
+        b = b.copy()
+        self.lib.orc3_direct_step(C.byref(p), len(b), _ptr(b), nsteps)
+        return b
+
+    def bh_bbox3(self, b, p=None):
+        p = p or self.params()
+        box = np.zeros(6)
+        self.lib.orc3_bh_bbox(C.byref(p), len(b), _ptr(b), _ptr(box))
+        return box
+
+    def bh_accel3(self, b, p=None, with_stats=False):
+        p = p or self.params()
+        acc = np.zeros((len(b), 3))
+        stats = np.zeros(4)
+        if self.lib.orc3_bh_accel(C.byref(p), len(b), _ptr(b), _ptr(acc), _ptr(stats)) != 0:
+            raise ValueError("coincident bodies")
+        return (acc, stats) if with_stats else acc
+
+    def bh_step3(self, b, nsteps, p=None):
+        p = p or self.params()
+        b = b.copy()
+        if self.lib.orc3_bh_step(C.byref(p), len(b), _ptr(b), nsteps) != 0:
+            raise ValueError("coincident bodies")
+        return b
+
+    def morton_keys3(self, b, box):
+        keys = np.zeros(len(b), dtype=np.uint64)
+        box = np.ascontiguousarray(box, dtype=np.float64)
+        self.lib.orc3_morton_keys(len(b), _ptr(b), _ptr(box), _ptr(keys))
+        return keys
 
     def morton_keys(self, b, box):
         keys = np.zeros(len(b), dtype=np.uint64)
