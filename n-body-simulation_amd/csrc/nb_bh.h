@@ -72,6 +72,25 @@ struct BhStepArgs {
     int collect_stats;
 };
 
+// Pieces the 3-D pipeline (nb_bh3.hip) shares.
+// Stable LSD radix sort of (key, index) pairs by key << 2, ping-pong between the two buffers;
+// the result is in buffer 0.  cut[2] = first pass with work (sort_first_pass in nb_dev.h); the
+// unsorted pairs must be in buffer cut[2] & 1.  hist: sort_hist_words(n) words, totals: 256.
+int sort_blocks(int n);
+size_t sort_hist_words(int n);
+int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], int n, const uint32_t *cut, uint32_t *hist,
+               uint32_t *totals);
+// Level-by-level tree over sorted keys whose digits (bits = 2: quadtree, 3: octree) start at bit
+// 61.  node_meta: {first body, count, first child, child count | cell level << 8}; split:
+// (n + 256) * build_split_bytes(bits) bytes; level_start: BH_MAX_DEPTH + 2 words; bsum:
+// BH_SCAN_BLOCKS words; counters: 8 words, zeroed here.
+size_t build_split_bytes(int bits);
+int launched_levels(const uint32_t *levels_host);
+int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node_meta, void *split, uint32_t *level_start,
+               uint32_t *bsum, unsigned long long *counters, int launched);
+// counters[2] = nodes, [3] = levels; *levels_host = levels (pinned host word).
+int bh_finish(hipStream_t s, const uint32_t *level_start, unsigned long long *counters, uint32_t *levels_host);
+
 // Individual stages (also driven one by one by the stage tests through nb_step).
 int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
 int bh_keys(hipStream_t s, BhBuffers &b, const BhStepArgs &a);

@@ -22,54 +22,9 @@
 #include <type_traits>
 
 #include "nb_bh.h"
+#include "nb_dev.h"
 
 namespace nb {
-
-// ------------------------------------------------------------------ helpers
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-
-// Exclusive scan of one int per thread over a 256-thread block; total = block sum.
-__device__ __forceinline__ int block_excl_scan_256(int v, int &total)
-{
-    __shared__ int wsum[4];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(incl, o);
-        if (lane >= o)
-            incl += t;
-    }
-    __syncthreads();  // protects wsum against the previous call's readers
-    if (lane == 63)
-        wsum[w] = incl;
-    __syncthreads();
-    int base = 0;
-    int tot = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int s = wsum[k];
-        if (k < w)
-            base += s;
-        tot += s;
-    }
-    total = tot;
-    return base + incl - v;
-}
-
-__device__ __forceinline__ int block_sum_256(int v)
-{
-    __shared__ int wsum2[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_xor(v, o);
-    __syncthreads();
-    if (lane_id() == 0)
-        wsum2[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3];
-}
 
 // ------------------------------------------------------------------ 1 bounding box
 
@@ -184,6 +139,7 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         cut[0] = first_closed;
         cut[1] = bucket_depth > 0 ? (uint32_t)bucket_depth
                                   : (first_closed < (uint32_t)BH_KEY_LEVELS ? first_closed : (uint32_t)BH_KEY_LEVELS);
+        cut[2] = (uint32_t)sort_first_pass(2 * (int)cut[1]);
     }
 }
 
@@ -205,9 +161,7 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 // 2*(below the y midpoint) + (right of the x midpoint), i.e. TL=0, TR=1, BL=2, BR=3.
 // Only the first cut[1] digits are computed, the rest of the key is zero: bodies of one cell of
 // that level then share a key and end up in one leaf.  The keys go to the buffer the first sort
-// pass that has work reads from (see bh_sort).
-__device__ __forceinline__ int first_sort_pass(uint32_t key_levels);
-
+// pass that has work (cut[2]) reads from (see sort_pairs).
 __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const double *box, const uint32_t *cut,
                                               uint64_t *keys0, uint64_t *keys1, uint32_t *idx0, uint32_t *idx1)
 {
@@ -229,7 +183,7 @@ __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const d
         bry = below ? bry : my;
         k = (k << 2) | ((uint64_t)below << 1) | (uint64_t)right;
     }
-    const bool odd = first_sort_pass((uint32_t)levels) & 1;
+    const bool odd = cut[2] & 1u;
     (odd ? keys1 : keys0)[i] = levels > 0 ? k << (2 * (BH_KEY_LEVELS - levels)) : 0ull;
     (odd ? idx1 : idx0)[i] = (uint32_t)i;
 }
@@ -257,16 +211,12 @@ constexpr int SORT_PASSES = (KEY_BITS + SORT_BITS - 1) / SORT_BITS;
 // The 62 key bits are sorted as the top of a 64-bit word (key << 2), eight bits a pass, so that the
 // passes line up with the TOP of the key: keys computed to `key_levels` digits are zero in the low
 // 64 - 2 key_levels bits of that word, and a pass whose digit lies wholly in there would move
-// nothing and returns at once (8 levels -> two passes with work, 9..12 -> three).  Pass p reads
+// nothing and returns at once (8 levels -> two passes with work, 9..12 -> three); the first pass
+// with work is left in cut[2] by the kernel that decides the key levels.  Pass p reads
 // buffer p & 1 and writes the other, so the last pass always leaves the result in buffer 0 and
 // the keys are written where the first pass with work reads them: the host launches the same
 // kernels every step and never needs to know how many did anything.
-__device__ __forceinline__ int first_sort_pass(uint32_t key_levels)
-{
-    const int zero_bits = 64 - 2 * (int)key_levels;
-    const int p = zero_bits / SORT_BITS;
-    return p < SORT_PASSES - 1 ? p : SORT_PASSES - 1;
-}
+static_assert(SORT_BITS == 8 && SORT_PASSES == 8, "sort_first_pass (nb_dev.h) assumes eight 8-bit passes");
 
 __device__ __forceinline__ uint32_t sort_digit(uint64_t key, int pass)
 {
@@ -276,7 +226,7 @@ __device__ __forceinline__ uint32_t sort_digit(uint64_t key, int pass)
 __global__ __launch_bounds__(256) void k_sort_count(const uint64_t *keys, int n, int pass, const uint32_t *cut,
                                                     uint32_t *hist, int nblk)
 {
-    if (pass < first_sort_pass(cut[1]))
+    if (pass < (int)cut[2])
         return;
     __shared__ uint32_t h[SORT_BINS];
     h[threadIdx.x] = 0;
@@ -333,7 +283,7 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *data, int count)
 __global__ __launch_bounds__(256) void k_scan_rows(uint32_t *hist, int nblk, uint32_t *totals, int pass,
                                                    const uint32_t *cut)
 {
-    if (pass < first_sort_pass(cut[1]))
+    if (pass < (int)cut[2])
         return;
     uint32_t *row = hist + (size_t)blockIdx.x * nblk;
     uint32_t running = 0;
@@ -358,7 +308,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
                                                       const uint32_t *cut, const uint32_t *hist, int nblk,
                                                       const uint32_t *totals)
 {
-    if (pass < first_sort_pass(cut[1]))
+    if (pass < (int)cut[2])
         return;
     __shared__ uint32_t wcnt[4][SORT_BINS];
     __shared__ uint32_t dbase[SORT_BINS];
@@ -445,22 +395,29 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
     }
 }
 
-int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+int sort_blocks(int n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+size_t sort_hist_words(int n) { return (size_t)SORT_BINS * sort_blocks(n); }
+
+int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], int n, const uint32_t *cut, uint32_t *hist,
+               uint32_t *totals)
 {
-    const int n = a.n;
-    const int nblk = b.sort_blocks;
+    const int nblk = sort_blocks(n);
     for (int pass = 0; pass < SORT_PASSES; ++pass) {
         const int in = pass & 1, out = in ^ 1;
-        hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, s, b.keys[in], n, pass, b.cut, b.hist, nblk);
-        hipLaunchKernelGGL(k_scan_rows, dim3(SORT_BINS), dim3(256), 0, s, b.hist, nblk, b.hist_totals, pass, b.cut);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, s, b.keys[in], b.idx[in], b.keys[out], b.idx[out], n,
-                           pass, b.cut, b.hist, nblk, b.hist_totals);
+        hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, s, keys[in], n, pass, cut, hist, nblk);
+        hipLaunchKernelGGL(k_scan_rows, dim3(SORT_BINS), dim3(256), 0, s, hist, nblk, totals, pass, cut);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, s, keys[in], idx[in], keys[out], idx[out], n, pass, cut,
+                           hist, nblk, totals);
     }
     static_assert(SORT_PASSES % 2 == 0, "the last pass must write buffer 0");
-    const int cur = 0;
-    b.sorted = cur;
     NB_HIP(hipGetLastError());
     return NB_OK;
+}
+
+int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+{
+    b.sorted = 0;
+    return sort_pairs(s, b.keys, b.idx, a.n, b.cut, b.hist, b.hist_totals);
 }
 
 // ------------------------------------------------------------------ 4 tree build
@@ -500,64 +457,91 @@ __device__ __forceinline__ void level_chunk(const uint32_t *level_start, int d, 
         cend = m;
 }
 
-// Quadrant boundaries of a node's body range: the first indices in [first, end) whose digit at
-// `shift` is >= 1, >= 2, >= 3 (digits are non-decreasing there).  The three binary searches
-// advance in lockstep, so their dependent loads overlap.
+// What the build keeps per frontier slot: the boundaries between a node's children in the sorted
+// order (3 for a quadtree, BITS = 2; 7 for an octree, BITS = 3) and child count | cell level << 8.
+template <int BITS>
+struct Split {
+    uint32_t s[(1 << BITS) - 1];
+    uint32_t w;
+};
+
+// Child boundaries of a node's body range: the first indices in [first, end) whose digit at
+// `shift` is >= 1, >= 2, ... (digits are non-decreasing there).  The binary searches advance in
+// lockstep, so their dependent loads overlap.
+template <int BITS>
 __device__ __forceinline__ void digit_boundaries(const uint64_t *keys, uint32_t first, uint32_t end, int shift,
-                                                 uint32_t &s1, uint32_t &s2, uint32_t &s3)
+                                                 uint32_t (&out)[(1 << BITS) - 1])
 {
-    uint32_t lo1 = first, hi1 = end, lo2 = first, hi2 = end, lo3 = first, hi3 = end;
-    while (lo1 < hi1 || lo2 < hi2 || lo3 < hi3) {
-        const uint32_t m1 = lo1 + ((hi1 - lo1) >> 1), m2 = lo2 + ((hi2 - lo2) >> 1), m3 = lo3 + ((hi3 - lo3) >> 1);
-        const uint32_t d1 = lo1 < hi1 ? (uint32_t)(keys[m1] >> shift) & 3u : 0u;
-        const uint32_t d2 = lo2 < hi2 ? (uint32_t)(keys[m2] >> shift) & 3u : 0u;
-        const uint32_t d3 = lo3 < hi3 ? (uint32_t)(keys[m3] >> shift) & 3u : 0u;
-        if (lo1 < hi1) {
-            if (d1 < 1u)
-                lo1 = m1 + 1;
-            else
-                hi1 = m1;
-        }
-        if (lo2 < hi2) {
-            if (d2 < 2u)
-                lo2 = m2 + 1;
-            else
-                hi2 = m2;
-        }
-        if (lo3 < hi3) {
-            if (d3 < 3u)
-                lo3 = m3 + 1;
-            else
-                hi3 = m3;
-        }
+    constexpr int NB = (1 << BITS) - 1;
+    constexpr uint32_t DMASK = (1u << BITS) - 1u;
+    uint32_t lo[NB], hi[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        lo[b] = first;
+        hi[b] = end;
     }
-    s1 = lo1;
-    s2 = lo2;
-    s3 = lo3;
+    for (;;) {
+        bool open = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            open = open || lo[b] < hi[b];
+        if (!open)
+            break;
+        uint32_t mid[NB], dg[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            mid[b] = lo[b] + ((hi[b] - lo[b]) >> 1);
+            dg[b] = lo[b] < hi[b] ? (uint32_t)(keys[mid[b]] >> shift) & DMASK : 0u;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (lo[b] < hi[b]) {
+                if (dg[b] < (uint32_t)(b + 1))
+                    lo[b] = mid[b] + 1;
+                else
+                    hi[b] = mid[b];
+            }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        out[b] = lo[b];
 }
 
 // The same boundaries found by G lanes together (G = 8 or 64, a power of two; the G lanes are
 // consecutive lanes of one wave and all call this with the same range): every round each lane
-// probes one of G evenly spaced positions of each of the three ranges, and the first lane whose
-// digit reaches the boundary's value narrows that range to the gap before its probe.
-template <int G>
+// probes one of G evenly spaced positions of each range, and the first lane whose digit reaches
+// the boundary's value narrows that range to the gap before its probe.
+template <int G, int BITS>
 __device__ __forceinline__ void digit_boundaries_group(const uint64_t *keys, uint32_t first, uint32_t end, int shift,
-                                                       uint32_t &s1, uint32_t &s2, uint32_t &s3)
+                                                       uint32_t (&out)[(1 << BITS) - 1])
 {
+    constexpr int NB = (1 << BITS) - 1;
+    constexpr uint32_t DMASK = (1u << BITS) - 1u;
     const int lane = threadIdx.x & 63, g = lane & (G - 1), gshift = lane & ~(G - 1);
     const uint64_t gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
-    uint32_t lo[3] = {first, first, first}, hi[3] = {end, end, end};
-    while (lo[0] < hi[0] || lo[1] < hi[1] || lo[2] < hi[2]) {
-        uint32_t probe[3];
-        bool reach[3];
+    uint32_t lo[NB], hi[NB];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < NB; ++b) {
+        lo[b] = first;
+        hi[b] = end;
+    }
+    for (;;) {
+        bool open = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            open = open || lo[b] < hi[b];
+        if (!open)
+            break;
+        uint32_t probe[NB];
+        bool reach[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
             const uint32_t len = hi[b] - lo[b];
             probe[b] = lo[b] + (uint32_t)(((uint64_t)len * (uint32_t)(g + 1)) / (uint32_t)(G + 1));
-            reach[b] = len > 0u && ((uint32_t)(keys[len > 0u ? probe[b] : first] >> shift) & 3u) >= (uint32_t)(b + 1);
+            reach[b] = len > 0u && ((uint32_t)(keys[len > 0u ? probe[b] : first] >> shift) & DMASK) >= (uint32_t)(b + 1);
         }
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const uint32_t len = hi[b] - lo[b];
             if (len == 0u)
                 continue;
@@ -569,56 +553,67 @@ __device__ __forceinline__ void digit_boundaries_group(const uint64_t *keys, uin
             hi[b] = at;
         }
     }
-    s1 = lo[0];
-    s2 = lo[1];
-    s3 = lo[2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        out[b] = lo[b];
 }
 
-// What a node becomes: its quadrant boundaries and child count | cell level << 8 (0 children for
+// What a node becomes: its child boundaries and child count | cell level << 8 (0 children for
 // a leaf: one body, or several bodies with one key).  G lanes call it together for one node.
-template <int G>
-__device__ __forceinline__ uint4 classify_node(const uint64_t *keys, uint4 meta)
+// Keys hold their digits from bit 61 down, BITS bits per level.
+template <int G, int BITS>
+__device__ __forceinline__ Split<BITS> classify_node(const uint64_t *keys, uint4 meta)
 {
+    constexpr int NB = (1 << BITS) - 1;
+    Split<BITS> sp;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        sp.s[b] = 0u;
+    sp.w = 0u;
     const uint32_t first = meta.x, count = meta.y, last = first + count - 1;
     const uint64_t kf = keys[first], kl = keys[last];
     if (count <= 1 || kf == kl)
-        return make_uint4(0u, 0u, 0u, 0u);
+        return sp;
     // level of the smallest cell holding the whole range: the first differing digit
-    const int lvl = (__clzll((long long)(kf ^ kl)) - 2) >> 1;
-    const int shift = KEY_BITS - 2 - 2 * lvl;
+    const int lvl = (__clzll((long long)(kf ^ kl)) - 2) / BITS;
+    const int shift = 62 - BITS - BITS * lvl;
     const uint32_t end = first + count;
-    uint32_t s1, s2, s3;
     if (G == 1)
-        digit_boundaries(keys, first, end, shift, s1, s2, s3);
+        digit_boundaries<BITS>(keys, first, end, shift, sp.s);
     else
-        digit_boundaries_group<G>(keys, first, end, shift, s1, s2, s3);
-    const uint32_t nchild = (s1 > first) + (s2 > s1) + (s3 > s2) + (end > s3);
-    return make_uint4(s1, s2, s3, nchild | ((uint32_t)lvl << 8));
+        digit_boundaries_group<G, BITS>(keys, first, end, shift, sp.s);
+    uint32_t nchild = (sp.s[0] > first) + (end > sp.s[NB - 1]);
+#pragma unroll
+    for (int b = 1; b < NB; ++b)
+        nchild += sp.s[b] > sp.s[b - 1];
+    sp.w = nchild | ((uint32_t)lvl << 8);
+    return sp;
 }
 
 // Writes a node's final metadata and the ranges of its children starting at slot cf.
-__device__ __forceinline__ void emit_children(uint4 *node_meta, uint32_t u, uint4 sp, uint32_t cf)
+template <int BITS>
+__device__ __forceinline__ void emit_children(uint4 *node_meta, uint32_t u, const Split<BITS> &sp, uint32_t cf)
 {
+    constexpr int NB = (1 << BITS) - 1;
     uint4 meta = node_meta[u];
     meta.z = cf;
     meta.w = sp.w;
     node_meta[u] = meta;
     if (sp.w & 0xffu) {
-        const uint32_t first = meta.x, end = meta.x + meta.y;
-        const uint32_t b0 = first, b1 = sp.x, b2 = sp.y, b3 = sp.z;
-        uint32_t c = cf;
-        if (b1 > b0)
-            node_meta[c++] = make_uint4(b0, b1 - b0, 0u, 0u);
-        if (b2 > b1)
-            node_meta[c++] = make_uint4(b1, b2 - b1, 0u, 0u);
-        if (b3 > b2)
-            node_meta[c++] = make_uint4(b2, b3 - b2, 0u, 0u);
-        if (end > b3)
-            node_meta[c++] = make_uint4(b3, end - b3, 0u, 0u);
+        const uint32_t end = meta.x + meta.y;
+        uint32_t c = cf, from = meta.x;
+#pragma unroll
+        for (int b = 0; b <= NB; ++b) {
+            const uint32_t to = b < NB ? sp.s[b] : end;
+            if (to > from)
+                node_meta[c++] = make_uint4(from, to - from, 0u, 0u);
+            from = to;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4 *node_meta, uint4 *split,
+template <int BITS>
+__global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4 *node_meta, Split<BITS> *split,
                                                      const uint32_t *level_start, uint32_t *bsum, int d)
 {
     uint32_t lbeg, m, cbeg, cend;
@@ -627,7 +622,7 @@ __global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4
     const int group = search_group(m);  // uniform over the grid
     if (group == 64) {
         for (uint32_t slot = cbeg + (threadIdx.x >> 6); slot < cend; slot += 4) {
-            const uint4 sp = classify_node<64>(keys, node_meta[lbeg + slot]);
+            const Split<BITS> sp = classify_node<64, BITS>(keys, node_meta[lbeg + slot]);
             if ((threadIdx.x & 63) == 0) {
                 local += (int)(sp.w & 0xffu);
                 split[slot] = sp;
@@ -637,9 +632,10 @@ __global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4
         // a wave's eight groups stay together until the last of them is done (they share ballots)
         for (uint32_t base = cbeg; base < cend; base += 32) {
             const uint32_t slot = base + (threadIdx.x >> 3);
-            uint4 sp = make_uint4(0u, 0u, 0u, 0u);
+            Split<BITS> sp;
+            sp.w = 0u;
             if (slot < cend)
-                sp = classify_node<8>(keys, node_meta[lbeg + slot]);
+                sp = classify_node<8, BITS>(keys, node_meta[lbeg + slot]);
             if (slot < cend && (threadIdx.x & 7) == 0) {
                 local += (int)(sp.w & 0xffu);
                 split[slot] = sp;
@@ -647,7 +643,7 @@ __global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4
         }
     } else {
         for (uint32_t slot = cbeg + threadIdx.x; slot < cend; slot += 256) {
-            const uint4 sp = classify_node<1>(keys, node_meta[lbeg + slot]);
+            const Split<BITS> sp = classify_node<1, BITS>(keys, node_meta[lbeg + slot]);
             local += (int)(sp.w & 0xffu);
             split[slot] = sp;
         }
@@ -657,8 +653,9 @@ __global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4
         bsum[blockIdx.x] = (uint32_t)tot;
 }
 
-__global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, uint2 *node_child, const uint4 *split,
-                                                    uint32_t *level_start, const uint32_t *bsum, int d)
+template <int BITS>
+__global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, const Split<BITS> *split, uint32_t *level_start,
+                                                    const uint32_t *bsum, int d)
 {
     uint32_t lbeg, m, cbeg, cend;
     level_chunk(level_start, d, lbeg, m, cbeg, cend);
@@ -679,14 +676,15 @@ __global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, uint2 *nod
     for (uint32_t tile = cbeg; tile < cend; tile += 256) {
         const uint32_t slot = tile + threadIdx.x;
         const bool valid = slot < cend;
-        uint4 sp = make_uint4(0u, 0u, 0u, 0u);
+        Split<BITS> sp;
+        sp.w = 0u;
         if (valid)
             sp = split[slot];
         const int nchild = (int)(sp.w & 0xffu);
         int tile_total;
         const int excl = block_excl_scan_256(nchild, tile_total);
         if (valid)
-            emit_children(node_meta, lbeg + slot, sp, running + (uint32_t)excl);
+            emit_children<BITS>(node_meta, lbeg + slot, sp, running + (uint32_t)excl);
         running += (uint32_t)tile_total;
     }
 }
@@ -695,8 +693,8 @@ __global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, uint2 *nod
 // levels as the previous steps' trees had (plus a margin) and lets this kernel finish whatever
 // is left -- normally nothing, so it returns at once; a tree that grew deeper is still built
 // completely, just by fewer threads.
-__global__ __launch_bounds__(256) void k_build_tail(const uint64_t *keys, uint4 *node_meta, uint4 *split,
-                                                    uint32_t *level_start, int d0)
+template <int BITS>
+__global__ __launch_bounds__(256) void k_build_tail(const uint64_t *keys, uint4 *node_meta, uint32_t *level_start, int d0)
 {
     for (int d = d0; d < BH_MAX_DEPTH - 2; ++d) {
         const uint32_t lbeg = level_start[d], m = level_start[d + 1] - lbeg;
@@ -705,13 +703,14 @@ __global__ __launch_bounds__(256) void k_build_tail(const uint64_t *keys, uint4 
         uint32_t running = level_start[d + 1];
         for (uint32_t tile = 0; tile < m; tile += 256) {
             const uint32_t slot = tile + threadIdx.x;
-            uint4 sp = make_uint4(0u, 0u, 0u, 0u);
+            Split<BITS> sp;
+            sp.w = 0u;
             if (slot < m)
-                sp = classify_node<1>(keys, node_meta[lbeg + slot]);
+                sp = classify_node<1, BITS>(keys, node_meta[lbeg + slot]);
             int tile_total;
             const int excl = block_excl_scan_256((int)(sp.w & 0xffu), tile_total);
             if (slot < m)
-                emit_children(node_meta, lbeg + slot, sp, running + (uint32_t)excl);
+                emit_children<BITS>(node_meta, lbeg + slot, sp, running + (uint32_t)excl);
             running += (uint32_t)tile_total;
         }
         __syncthreads();
@@ -720,35 +719,51 @@ __global__ __launch_bounds__(256) void k_build_tail(const uint64_t *keys, uint4 
         __threadfence_block();
         __syncthreads();
     }
-    (void)split;
 }
 
 // Tree levels the per-level kernels are launched for: what the last finished step needed (the
 // device leaves that number in host-visible memory; reading a stale one only costs speed) plus a
 // margin, everything on the first steps.
-static int launched_levels(const BhBuffers &b)
+int launched_levels(const uint32_t *levels_host)
 {
-    const uint32_t seen = b.levels_host ? *(volatile uint32_t *)b.levels_host : 0u;
+    const uint32_t seen = levels_host ? *(volatile const uint32_t *)levels_host : 0u;
     int l = seen == 0u ? BH_MAX_DEPTH - 2 : (int)seen + 1;
     if (l > BH_MAX_DEPTH - 2)
         l = BH_MAX_DEPTH - 2;
     return l;
 }
 
-int bh_build(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+size_t build_split_bytes(int bits) { return bits == 3 ? sizeof(Split<3>) : sizeof(Split<2>); }
+
+template <int BITS>
+static void launch_build(hipStream_t s, const uint64_t *keys, int n, uint4 *node_meta, void *split, uint32_t *level_start,
+                         uint32_t *bsum, unsigned long long *counters, int launched)
 {
-    const uint64_t *keys = b.keys[b.sorted];
-    hipLaunchKernelGGL(k_build_init, dim3(1), dim3(64), 0, s, b.node_meta, b.level_start, a.n, b.counters);
-    b.launched = launched_levels(b);
-    for (int d = 0; d < b.launched; ++d) {
-        hipLaunchKernelGGL(k_build_count, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, keys, b.node_meta, b.split,
-                           b.level_start, b.bsum, d);
-        hipLaunchKernelGGL(k_build_emit, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, b.node_meta, b.node_child, b.split,
-                           b.level_start, b.bsum, d);
+    hipLaunchKernelGGL(k_build_init, dim3(1), dim3(64), 0, s, node_meta, level_start, n, counters);
+    for (int d = 0; d < launched; ++d) {
+        hipLaunchKernelGGL(k_build_count<BITS>, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, keys, node_meta, (Split<BITS> *)split,
+                           level_start, bsum, d);
+        hipLaunchKernelGGL(k_build_emit<BITS>, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, node_meta,
+                           (const Split<BITS> *)split, level_start, bsum, d);
     }
-    hipLaunchKernelGGL(k_build_tail, dim3(1), dim3(256), 0, s, keys, b.node_meta, b.split, b.level_start, b.launched);
+    hipLaunchKernelGGL(k_build_tail<BITS>, dim3(1), dim3(256), 0, s, keys, node_meta, level_start, launched);
+}
+
+int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node_meta, void *split, uint32_t *level_start,
+               uint32_t *bsum, unsigned long long *counters, int launched)
+{
+    if (bits == 3)
+        launch_build<3>(s, keys, n, node_meta, split, level_start, bsum, counters, launched);
+    else
+        launch_build<2>(s, keys, n, node_meta, split, level_start, bsum, counters, launched);
     NB_HIP(hipGetLastError());
     return NB_OK;
+}
+
+int bh_build(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+{
+    b.launched = launched_levels(b.levels_host);
+    return build_tree(s, 2, b.keys[b.sorted], a.n, b.node_meta, b.split, b.level_start, b.bsum, b.counters, b.launched);
 }
 
 // ------------------------------------------------------------------ 5 centre of mass
@@ -1490,6 +1505,13 @@ __global__ void k_bh_finish_counters(const uint32_t *level_start, unsigned long 
     }
 }
 
+int bh_finish(hipStream_t s, const uint32_t *level_start, unsigned long long *counters, uint32_t *levels_host)
+{
+    hipLaunchKernelGGL(k_bh_finish_counters, dim3(1), dim3(64), 0, s, level_start, counters, levels_host);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
 int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     ForceArgs f;
@@ -1544,9 +1566,7 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
         else
             hipLaunchKernelGGL((k_bh_force<FM_NOEPS, false>), grid, dim3(256), 0, s, f);
     }
-    hipLaunchKernelGGL(k_bh_finish_counters, dim3(1), dim3(64), 0, s, b.level_start, b.counters, b.levels_host);
-    NB_HIP(hipGetLastError());
-    return NB_OK;
+    return bh_finish(s, b.level_start, b.counters, b.levels_host);
 }
 
 // ------------------------------------------------------------------ buffers
@@ -1566,9 +1586,9 @@ int bh_alloc(BhBuffers &b, int n)
 {
     b.n = n;
     b.node_cap = 2 * (size_t)n + 8;
-    b.sort_blocks = (n + SORT_TILE - 1) / SORT_TILE;
+    b.sort_blocks = sort_blocks(n);
     NB_TRY(dev_alloc(b.box, 4));
-    NB_TRY(dev_alloc(b.cut, 2));
+    NB_TRY(dev_alloc(b.cut, 4));
     NB_TRY(dev_alloc(b.leaf_sum, 4 * (size_t)n));
     NB_TRY(dev_alloc(b.bbox_part, 4 * BBOX_BLOCKS));
     for (int k = 0; k < 2; ++k) {
@@ -1579,7 +1599,7 @@ int bh_alloc(BhBuffers &b, int n)
     NB_TRY(dev_alloc(b.hist_totals, SORT_BINS));
     NB_TRY(dev_alloc(b.posm_s, (size_t)n));
     NB_TRY(dev_alloc(b.node_meta, b.node_cap));
-    NB_TRY(dev_alloc(b.split, (size_t)n + 256));
+    NB_TRY(dev_alloc(b.split, (size_t)n + 256));  // one Split<2> (16 bytes) per frontier slot
     NB_TRY(dev_alloc(b.level_start, BH_MAX_DEPTH + 2));
     NB_TRY(dev_alloc(b.bsum, BH_SCAN_BLOCKS));
     NB_TRY(dev_alloc(b.node_com, 4 * b.node_cap));

@@ -1,0 +1,61 @@
+// nb_dev.h -- device helpers shared by the Barnes-Hut sources (2-D and 3-D).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace nb {
+
+static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Exclusive scan of one int per thread over a 256-thread block; total = block sum.
+static __device__ __forceinline__ int block_excl_scan_256(int v, int &total)
+{
+    __shared__ int wsum[4];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if (lane >= o)
+            incl += t;
+    }
+    __syncthreads();  // protects wsum against the previous call's readers
+    if (lane == 63)
+        wsum[w] = incl;
+    __syncthreads();
+    int base = 0;
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int s = wsum[k];
+        if (k < w)
+            base += s;
+        tot += s;
+    }
+    total = tot;
+    return base + incl - v;
+}
+
+static __device__ __forceinline__ int block_sum_256(int v)
+{
+    __shared__ int wsum2[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lane_id() == 0)
+        wsum2[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3];
+}
+
+// The radix sort (sort_pairs) orders key << 2 by eight 8-bit digits, lowest first.  Keys whose
+// digits fill only the top `used_bits` bits of that word are zero below, and the passes over
+// those zero digits would move nothing: this is the first pass that has work.
+static __host__ __device__ __forceinline__ int sort_first_pass(int used_bits)
+{
+    const int p = (64 - used_bits) / 8;
+    return p < 7 ? p : 7;
+}
+
+}  // namespace nb
