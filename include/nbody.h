@@ -208,6 +208,58 @@ int nb_refresh_order(nb_sim *sim);
  * the pairs the force law does not skip (NaN when n > 131072: it is an O(n^2) sum). */
 int nb_diagnostics(nb_sim *sim, double *out, int count);
 
+/* ==== three dimensions ====
+ *
+ * The reference is two-dimensional (struct Vector holds x and y, src/cpu/vector.h); its authors
+ * name 3-D with an octree as future work.  The nb3_ entry points run the same rules with a
+ * third coordinate: distance sqrt(dx^2+dy^2+dz^2+eps^2), the same cutoff tests, and for
+ * Barnes-Hut an octree with one body per leaf whose cells are split at the midpoint of every
+ * axis (z treated like y in QuadTree::getQuadrant, src/cpu/quadtree.cpp:41-72), children taken
+ * in the order 4 (lower z) + 2 (lower y) + (right x), opening test cell x-width / distance <
+ * theta (src/cpu/barnesHut.cpp:70-71).  For bodies that all lie in the plane z = 0 the results
+ * are those of the 2-D entry points.  One GPU per simulation; nb_params.bucket_depth must be 0.
+ * Each nb3_ function mirrors the nb_ function of the same name. */
+
+typedef struct nb_vec3 {
+    double x;
+    double y;
+    double z;
+} nb_vec3;
+
+/* The reference's Body with three-component vectors: 96 bytes (isDynamic@0, mass@8, radius@16,
+ * position@24, velocity@48, acceleration@72). */
+typedef struct nb_body3 {
+    uint8_t is_dynamic;
+    uint8_t pad_[7];
+    double mass;
+    double radius;
+    nb_vec3 position;
+    nb_vec3 velocity;
+    nb_vec3 acceleration;
+} nb_body3;
+
+typedef struct nb_sim3 nb_sim3; /* opaque */
+
+/* Host only: nb_init_scenario(sim, n, seed) (identical x, y and velocities), then one more rand()
+ * per body in index order: z = thickness (2 u - 1), except that the suns stay at z = 0; vz = 0. */
+int nb3_init_scenario(int sim, int n, unsigned seed, double thickness, nb_body3 *out);
+
+int nb3_create(const nb_params *params, int n, int alg, nb_sim3 **out);
+int nb3_destroy(nb_sim3 *sim);
+int nb3_setup(nb_sim3 *sim, int scenario, unsigned seed, double thickness);
+int nb3_set_bodies(nb_sim3 *sim, const nb_body3 *bodies, int n);
+int nb3_step(nb_sim3 *sim, int nsteps);
+int nb3_compute_accel(nb_sim3 *sim);
+int nb3_read_bodies(nb_sim3 *sim, nb_body3 *out);
+int nb3_sync(nb_sim3 *sim);
+/* `which` is an nb_debug_array.  Differences from nb_debug_read: NB_DBG_BBOX is 6 doubles
+ * (topLeft.x, topLeft.y, botRight.x, botRight.y, upper z, lower z); keys hold 3 bits per level from
+ * bit 61 down (at most 20 levels); NB_DBG_NODE_COM is 6 doubles per node (com.x, com.y, com.z, mass,
+ * cell x-width or minus the body's radius, 0); NB_DBG_KEYS is not available. */
+int nb3_debug_read(nb_sim3 *sim, int which, void *out, size_t bytes, size_t *written);
+int nb3_set_stage_timing(nb_sim3 *sim, int on);
+int nb3_stage_ms(nb_sim3 *sim, float *out, int count);
+
 const char *nb_last_error(void);
 const char *nb_version(void);
 

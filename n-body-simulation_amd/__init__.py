@@ -38,6 +38,16 @@ BODY_DTYPE = np.dtype(
     }
 )
 
+# nb_body3: the same fields with three-component vectors, 96 bytes.
+BODY3_DTYPE = np.dtype(
+    {
+        "names": ["is_dynamic", "mass", "radius", "pos", "vel", "acc"],
+        "formats": [np.uint8, np.float64, np.float64, (np.float64, 3), (np.float64, 3), (np.float64, 3)],
+        "offsets": [0, 8, 16, 24, 48, 72],
+        "itemsize": 96,
+    }
+)
+
 DBG_BBOX, DBG_KEYS, DBG_SORTED_KEYS, DBG_SORTED_IDX = 0, 1, 2, 3
 DBG_NODE_RANGE, DBG_NODE_CHILD, DBG_NODE_COM, DBG_LEVEL_START, DBG_ORDER, DBG_COUNTERS = 4, 5, 6, 7, 8, 9
 DBG_KEY_LEVELS = 10
@@ -48,6 +58,8 @@ ABI_SYMBOLS = [
     "nb_step", "nb_compute_accel", "nb_read_bodies", "nb_sync", "nb_set_stream", "nb_set_partition",
     "nb_exchange_buffer", "nb_step_local", "nb_step_finish", "nb_debug_read", "nb_set_stage_timing",
     "nb_stage_ms", "nb_diagnostics", "nb_refresh_order", "nb_last_error", "nb_version",
+    "nb3_init_scenario", "nb3_create", "nb3_destroy", "nb3_setup", "nb3_set_bodies", "nb3_step",
+    "nb3_compute_accel", "nb3_read_bodies", "nb3_sync", "nb3_debug_read", "nb3_set_stage_timing", "nb3_stage_ms",
 ]
 
 
@@ -105,6 +117,18 @@ def load_library(path=None):
     lib.nb_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]
     lib.nb_diagnostics.argtypes = [vp, C.POINTER(C.c_double), i]
     lib.nb_refresh_order.argtypes = [vp]
+    lib.nb3_init_scenario.argtypes = [i, i, u, C.c_double, vp]
+    lib.nb3_create.argtypes = [C.POINTER(Params), i, i, C.POINTER(vp)]
+    lib.nb3_destroy.argtypes = [vp]
+    lib.nb3_setup.argtypes = [vp, i, u, C.c_double]
+    lib.nb3_set_bodies.argtypes = [vp, vp, i]
+    lib.nb3_step.argtypes = [vp, i]
+    lib.nb3_compute_accel.argtypes = [vp]
+    lib.nb3_read_bodies.argtypes = [vp, vp]
+    lib.nb3_sync.argtypes = [vp]
+    lib.nb3_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.nb3_set_stage_timing.argtypes = [vp, i]
+    lib.nb3_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]
     lib.nb_last_error.restype = C.c_char_p
     lib.nb_version.restype = C.c_char_p
     for name in ABI_SYMBOLS:
@@ -229,6 +253,84 @@ class NBodySim:
     def close(self):
         if self._h:
             self._lib.nb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def init_scenario3(sim, n, seed=12345, thickness=0.0):
+    """The 2-D scenario with a height per body drawn from [-thickness, thickness] (suns stay at z = 0)."""
+    m = 5 if sim == SOLAR else n
+    b = np.zeros(m, dtype=BODY3_DTYPE)
+    _check(load_library().nb3_init_scenario(sim, m, seed, thickness, b.ctypes.data_as(C.c_void_p)))
+    return b
+
+
+class NBodySim3:
+    """NBodySim for three-dimensional bodies (the nb3_ entry points; one GPU)."""
+
+    def __init__(self, n, alg=BARNES_HUT, params=None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.n = int(n)
+        self.alg = alg
+        self.params = params or default_params()
+        _check(self._lib.nb3_create(C.byref(self.params), self.n, alg, C.byref(self._h)))
+
+    def setup(self, sim, seed=12345, thickness=0.0):
+        _check(self._lib.nb3_setup(self._h, sim, seed, thickness))
+
+    def update(self, nsteps=1):
+        _check(self._lib.nb3_step(self._h, nsteps))
+
+    def read_bodies(self):
+        out = np.zeros(self.n, dtype=BODY3_DTYPE)
+        _check(self._lib.nb3_read_bodies(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_bodies(self, bodies):
+        b = np.ascontiguousarray(bodies, dtype=BODY3_DTYPE)
+        _check(self._lib.nb3_set_bodies(self._h, b.ctypes.data_as(C.c_void_p), len(b)))
+
+    def compute_accel(self):
+        _check(self._lib.nb3_compute_accel(self._h))
+        return self.read_bodies()["acc"]
+
+    def sync(self):
+        _check(self._lib.nb3_sync(self._h))
+
+    def set_stage_timing(self, on=True, counters=None):
+        counters = on if counters is None else counters
+        _check(self._lib.nb3_set_stage_timing(self._h, (1 if on else 0) | (2 if counters else 0)))
+
+    def stage_ms(self):
+        out = (C.c_float * 8)()
+        _check(self._lib.nb3_stage_ms(self._h, out, 8))
+        names = ["bbox", "keys", "sort", "build", "com", "force", "other"]
+        return {k: out[i] for i, k in enumerate(names)}
+
+    def order(self):
+        return self.debug(DBG_ORDER, np.uint32, self.n)
+
+    def debug(self, which, dtype, count):
+        out = np.zeros(count, dtype=dtype)
+        w = C.c_size_t()
+        _check(self._lib.nb3_debug_read(self._h, which, out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(w)))
+        return out[: w.value // out.itemsize]
+
+    def close(self):
+        if self._h:
+            self._lib.nb3_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -1,0 +1,905 @@
+// nb_bh3.hip -- the Barnes-Hut pipeline of nb_bh.hip for three dimensions (see nb_dim3.h for the
+// rules it follows).  Same stages on one stream, no host synchronisation in between:
+//   1 bbox   min/max of the three coordinates, rounded to float and padded as
+//            BarnesHut::computeBoundingBox pads x and y (barnesHut.cpp:23-35)
+//   2 keys   octant paths by the FP64 midpoint descent of QuadTree::getQuadrant
+//            (quadtree.cpp:41-72) on three axes: digit = 4 (below mid z) + 2 (below mid y) +
+//            (right of mid x), 3 bits per level, at most 20 levels
+//   3 sort   the radix sort of nb_bh.hip
+//   4 build  the level-by-level build of nb_bh.hip with 3-bit digits (up to 8 children)
+//   5 com    bottom-up centres of mass, children summed in digit order
+//   6 force  one wave per 64 Morton-consecutive bodies with a shared stack in LDS, every lane
+//            applying its own opening test, fused integration
+// As in 2-D, cells that no body can ever open (width / theta + diagonal < collision_th) are not
+// built below: the keys stop at that level and its cells become leaves holding several bodies.
+#include <type_traits>
+
+#include "nb_bh.h"
+#include "nb_dev.h"
+#include "nb_dim3.h"
+
+namespace nb {
+
+// ------------------------------------------------------------------ 1 bounding box
+
+constexpr int BBOX3_BLOCKS = 1024;
+
+struct MinMax3 {
+    double lo[3], hi[3];
+};
+
+__device__ __forceinline__ void mm_init(MinMax3 &m)
+{
+    for (int d = 0; d < 3; ++d) {
+        m.lo[d] = __builtin_inf();
+        m.hi[d] = -__builtin_inf();
+    }
+}
+
+// Folds the block's values; the result is valid in thread 0.
+__device__ __forceinline__ void mm_block_reduce(MinMax3 &m)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            m.lo[d] = fmin(m.lo[d], __shfl_xor(m.lo[d], o));
+            m.hi[d] = fmax(m.hi[d], __shfl_xor(m.hi[d], o));
+        }
+    __shared__ double sh[4][6];
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0)
+        for (int d = 0; d < 3; ++d) {
+            sh[w][d] = m.lo[d];
+            sh[w][3 + d] = m.hi[d];
+        }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 1; k < 4; ++k)
+            for (int d = 0; d < 3; ++d) {
+                m.lo[d] = fmin(m.lo[d], sh[k][d]);
+                m.hi[d] = fmax(m.hi[d], sh[k][3 + d]);
+            }
+}
+
+__global__ __launch_bounds__(256) void k_bbox3_partial(const double *pos, int n, double *part)
+{
+    MinMax3 m;
+    mm_init(m);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        for (int d = 0; d < 3; ++d) {
+            const double v = pos[3 * (size_t)i + d];
+            m.lo[d] = fmin(m.lo[d], v);
+            m.hi[d] = fmax(m.hi[d], v);
+        }
+    mm_block_reduce(m);
+    if (threadIdx.x == 0)
+        for (int d = 0; d < 3; ++d) {
+            part[6 * blockIdx.x + d] = m.lo[d];
+            part[6 * blockIdx.x + 3 + d] = m.hi[d];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_bbox3_final(const double *part, int nblk, double margin, double theta, double cth,
+                                                     double *box, uint32_t *cut)
+{
+    MinMax3 m;
+    mm_init(m);
+    for (int i = threadIdx.x; i < nblk; i += 256)
+        for (int d = 0; d < 3; ++d) {
+            m.lo[d] = fmin(m.lo[d], part[6 * i + d]);
+            m.hi[d] = fmax(m.hi[d], part[6 * i + 3 + d]);
+        }
+    mm_block_reduce(m);
+    if (threadIdx.x == 0) {
+        // every candidate passes through fminf/fmaxf in the reference (barnesHut.cpp:28-31);
+        // rounding is monotone, so rounding the extreme gives the same box
+        box[0] = (double)(float)(m.lo[0] - margin);  // topLeft.x
+        box[1] = (double)(float)(m.hi[1] + margin);  // topLeft.y
+        box[2] = (double)(float)(m.hi[0] + margin);  // botRight.x
+        box[3] = (double)(float)(m.lo[1] - margin);  // botRight.y
+        box[4] = (double)(float)(m.hi[2] + margin);  // upper z
+        box[5] = (double)(float)(m.lo[2] - margin);  // lower z
+        // First level whose cells no body ever opens: a cell is opened by a body that neither
+        // accepts it (dist <= width / theta) nor sees it wholly inside its cutoff distance
+        // (dist >= collision_th - diagonal); when width / theta < collision_th - diagonal no
+        // distance does both.  The margins cover the float rounding of the two thresholds.
+        uint32_t first_closed = 32u;
+        const double w0 = box[2] - box[0], h0 = box[1] - box[3], d0 = box[4] - box[5];
+        for (int l = BH3_KEY_LEVELS; l >= 0; --l) {
+            const double w = ldexp(w0, -l), h = ldexp(h0, -l), dz = ldexp(d0, -l);
+            const double reach = cth * (1.0 - 1.0e-4) - sqrt(w * w + h * h + dz * dz);
+            if (reach > 0.0 && reach * (1.0 - 1.0e-4) > w / theta)
+                first_closed = (uint32_t)l;
+            else
+                break;  // cells only grow from here up
+        }
+        cut[0] = first_closed;
+        cut[1] = first_closed < (uint32_t)BH3_KEY_LEVELS ? first_closed : (uint32_t)BH3_KEY_LEVELS;
+        cut[2] = (uint32_t)sort_first_pass(3 * (int)cut[1]);
+    }
+}
+
+int bh3_bbox(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
+{
+    int blocks = (a.n + 255) / 256;
+    if (blocks > BBOX3_BLOCKS)
+        blocks = BBOX3_BLOCKS;
+    hipLaunchKernelGGL(k_bbox3_partial, dim3(blocks), dim3(256), 0, s, a.pos, a.n, b.bbox_part);
+    hipLaunchKernelGGL(k_bbox3_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, a.theta, a.collision_th,
+                       b.box, b.cut);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------ 2 keys
+
+// The digit of level l occupies bits [61-3l, 59-3l] of the key word; only the first cut[1]
+// digits are computed.  The pairs go to the buffer the first sort pass with work reads.
+__global__ __launch_bounds__(256) void k_keys3(const double *pos, int n, const double *box, const uint32_t *cut,
+                                               uint64_t *keys0, uint64_t *keys1, uint32_t *idx0, uint32_t *idx1)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const int levels = (int)cut[1];
+    double tlx = box[0], tly = box[1], brx = box[2], bry = box[3], zup = box[4], zlo = box[5];
+    const double px = pos[3 * (size_t)i], py = pos[3 * (size_t)i + 1], pz = pos[3 * (size_t)i + 2];
+    uint64_t k = 0;
+#pragma unroll 1
+    for (int l = 0; l < levels; ++l) {
+        const double mx = (tlx + brx) / 2.0, my = (tly + bry) / 2.0, mz = (zup + zlo) / 2.0;
+        const bool right = !(mx >= px);  // getQuadrant: mid >= x is the left half
+        const bool ylow = !(my <= py);   // mid <= y is the top half
+        const bool zlow = !(mz <= pz);   // z like y
+        tlx = right ? mx : tlx;
+        brx = right ? brx : mx;
+        tly = ylow ? my : tly;
+        bry = ylow ? bry : my;
+        zup = zlow ? mz : zup;
+        zlo = zlow ? zlo : mz;
+        k = (k << 3) | ((uint64_t)zlow << 2) | ((uint64_t)ylow << 1) | (uint64_t)right;
+    }
+    const bool odd = cut[2] & 1u;
+    (odd ? keys1 : keys0)[i] = levels > 0 ? k << (2 + 3 * (BH3_KEY_LEVELS - levels)) : 0ull;
+    (odd ? idx1 : idx0)[i] = (uint32_t)i;
+}
+
+int bh3_keys(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
+{
+    hipLaunchKernelGGL(k_keys3, dim3((a.n + 255) / 256), dim3(256), 0, s, a.pos, a.n, b.box, b.cut, b.keys[0], b.keys[1],
+                       b.idx[0], b.idx[1]);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------ 3 sort, 4 build
+
+int bh3_sort(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
+{
+    return sort_pairs(s, b.keys, b.idx, a.n, b.cut, b.hist, b.hist_totals);
+}
+
+int bh3_build(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
+{
+    b.launched = launched_levels(b.levels_host);
+    return build_tree(s, 3, b.keys[0], a.n, b.node_meta, b.split, b.level_start, b.bsum, b.counters, b.launched);
+}
+
+// ------------------------------------------------------------------ 5 centre of mass
+
+struct Com3Args {
+    const uint4 *node_meta;
+    const uint32_t *level_start;
+    const uint32_t *idx;
+    const double *pos;
+    const double *mass;
+    const double *radius;
+    const float4 *posm_s;
+    const double *box;
+    double *node_com;
+    float4 *node_rec;
+    uint4 *node_aux;
+    const uint32_t *cut;
+    const double *leaf_sum;
+    double inv_len, inv_mass, theta, cth;
+};
+
+// Width, opening threshold and prune threshold of a cell of level lvl.
+__device__ __forceinline__ void cell_record3(const Com3Args &a, int lvl, double &width, float &open2, float &prune)
+{
+    width = ldexp(a.box[2] - a.box[0], -lvl);  // the cell's x-width, as QuadTree::getWidth (quadtree.cpp:234-237)
+    const double wt = width * a.inv_len / a.theta;  // width / dist < theta  <=>  dist > width / theta
+    open2 = (float)(wt * wt);
+    // the centre of mass lies inside the cell, so every point of the cell is within
+    // dist(com) + diagonal of a target: below collision_th nothing in the cell can contribute
+    const double h = ldexp(a.box[1] - a.box[3], -lvl), dz = ldexp(a.box[4] - a.box[5], -lvl);
+    const double reach = a.cth * (1.0 - 1.0e-4) - sqrt(width * width + h * h + dz * dz);
+    prune = reach > 0.0 ? (float)((reach * a.inv_len) * (reach * a.inv_len)) : -1.f;
+}
+
+__device__ __forceinline__ void store_node3(const Com3Args &a, uint32_t u, const uint4 meta, const double (&c)[3], double mtot,
+                                            double width, float open2, float prune)
+{
+    double2 *o = (double2 *)a.node_com + 3 * (size_t)u;
+    o[0] = make_double2(c[0], c[1]);
+    o[1] = make_double2(c[2], mtot);
+    o[2] = make_double2(width, 0.0);
+    a.node_rec[u] = make_float4((float)(c[0] * a.inv_len), (float)(c[1] * a.inv_len), (float)(c[2] * a.inv_len),
+                                (float)(mtot * a.inv_mass));
+    a.node_aux[u] = make_uint4(__float_as_uint(open2), (meta.z << 4) | (meta.w & 0xffu), __float_as_uint(prune), 0u);
+}
+
+// Sums over every run of bodies with one key (= every leaf with several bodies), left at the
+// run's first sorted position as {sum m x, sum m y, sum m z, sum m, max radius}; also writes
+// every body's float record in sorted order.  One wave per 64 consecutive sorted bodies, as
+// k_leaf_sums in nb_bh.hip.
+__global__ __launch_bounds__(256) void k_leaf_sums3(const uint64_t *keys, const uint32_t *idx, int n, const double *pos,
+                                                    const double *mass, const double *radius, double inv_len, double inv_mass,
+                                                    float4 *posm_s, float *rad_s, double *leaf_sum)
+{
+    const int lane = lane_id();
+    const int chunk = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (chunk >= n)
+        return;
+    const int k = chunk + lane;
+    const bool valid = k < n;
+    const uint64_t key = valid ? keys[k] : ~0ull;
+    const uint64_t prev = (valid && k > 0) ? keys[k - 1] : ~0ull;  // ~0 is no key (its low bits are set)
+    double sm = 0.0, sx = 0.0, sy = 0.0, sz = 0.0, rm = 0.0;
+    if (valid) {
+        const uint32_t o = idx[k];
+        const double px = pos[3 * (size_t)o], py = pos[3 * (size_t)o + 1], pz = pos[3 * (size_t)o + 2];
+        sm = mass[o];
+        sx = px * sm;
+        sy = py * sm;
+        sz = pz * sm;
+        rm = radius[o];
+        posm_s[k] = make_float4((float)(px * inv_len), (float)(py * inv_len), (float)(pz * inv_len), (float)(sm * inv_mass));
+        rad_s[k] = (float)(rm * inv_len);
+    }
+    const uint64_t heads = __builtin_amdgcn_ballot_w64(valid && (k == 0 || key != prev));
+    if (heads == 0ull)
+        return;  // the whole chunk lies inside a run that started earlier: that run's wave sums it
+    const uint64_t upto = heads & ((2ull << lane) - 1ull);
+    const int start = upto ? 63 - __builtin_clzll(upto) : -1;
+    const int dist = start >= 0 ? lane - start : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double tm = __shfl_up(sm, o), tx = __shfl_up(sx, o), ty = __shfl_up(sy, o), tz = __shfl_up(sz, o),
+                     tr = __shfl_up(rm, o);
+        if (o <= dist) {
+            sm += tm;
+            sx += tx;
+            sy += ty;
+            sz += tz;
+            rm = fmax(rm, tr);
+        }
+    }
+    const bool last_in_chunk = lane == 63 || !valid || ((heads >> (lane + 1)) & 1ull) || k + 1 >= n;
+    const bool ends = valid && start >= 0 && last_in_chunk;
+    const int tail = chunk + 64;
+    const uint64_t last_key = (uint64_t)__shfl(key, 63);
+    const bool goes_on = tail < n && keys[tail] == last_key;  // uniform
+    if (ends && !(lane == 63 && goes_on) && dist > 0) {
+        double *o = leaf_sum + 6 * (size_t)(chunk + start);
+        o[0] = sx;
+        o[1] = sy;
+        o[2] = sz;
+        o[3] = sm;
+        o[4] = rm;
+    }
+    const int start63 = __shfl(start, 63);
+    if (goes_on && start63 >= 0) {
+        double pm = 0.0, px = 0.0, py = 0.0, pz = 0.0, pr = 0.0;
+        for (int base = tail; base < n; base += 64) {
+            const int kk = base + lane;
+            const bool in = kk < n && keys[kk] == last_key;
+            if (in) {
+                const uint32_t o = idx[kk];
+                const double m = mass[o];
+                pm += m;
+                px += pos[3 * (size_t)o] * m;
+                py += pos[3 * (size_t)o + 1] * m;
+                pz += pos[3 * (size_t)o + 2] * m;
+                pr = fmax(pr, radius[o]);
+            }
+            if (__builtin_amdgcn_ballot_w64(in) != ~0ull)
+                break;  // the run ended inside these 64
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            pm += __shfl_xor(pm, o);
+            px += __shfl_xor(px, o);
+            py += __shfl_xor(py, o);
+            pz += __shfl_xor(pz, o);
+            pr = fmax(pr, __shfl_xor(pr, o));
+        }
+        const double hx = __shfl(sx, 63), hy = __shfl(sy, 63), hz = __shfl(sz, 63), hm = __shfl(sm, 63), hr = __shfl(rm, 63);
+        if (lane == 0) {
+            double *o = leaf_sum + 6 * (size_t)(chunk + start63);
+            o[0] = hx + px;
+            o[1] = hy + py;
+            o[2] = hz + pz;
+            o[3] = hm + pm;
+            o[4] = fmax(hr, pr);
+        }
+    }
+}
+
+// Centres of mass, masses and traversal records of the nodes of tree level d (children first).
+__device__ __forceinline__ void com3_level(const Com3Args &a, int d)
+{
+    const uint32_t lbeg = a.level_start[d], lend = a.level_start[d + 1];
+    for (uint32_t u = lbeg + blockIdx.x * 256 + threadIdx.x; u < lend; u += gridDim.x * 256) {
+        const uint4 meta = a.node_meta[u];
+        const uint32_t nchild = meta.w & 0xffu;
+        double c[3], mtot, width;
+        float open2, prune = -1.f;
+        if (nchild == 0) {
+            const uint32_t first = meta.x, count = meta.y;
+            if (count == 1) {
+                const uint32_t o = a.idx[first];
+                for (int k = 0; k < 3; ++k)
+                    c[k] = a.pos[3 * (size_t)o + k];
+                mtot = a.mass[o];
+                open2 = -(float)((a.radius[o] + a.cth) * a.inv_len);
+                width = -a.radius[o];
+            } else {
+                const double *ls = a.leaf_sum + 6 * (size_t)first;
+                mtot = ls[3];
+                for (int k = 0; k < 3; ++k)
+                    c[k] = ls[k] / mtot;
+                const uint32_t closed_level = a.cut[0];
+                if (closed_level <= (uint32_t)BH3_KEY_LEVELS) {
+                    // the bodies of a cell no body ever opens: a cell record, no children
+                    cell_record3(a, (int)closed_level, width, open2, prune);
+                } else {
+                    // bodies equal in all key levels: they act as one body
+                    open2 = -(float)((ls[4] + a.cth) * a.inv_len);
+                    width = -ls[4];
+                }
+            }
+        } else {
+            // updateCenterMass: total = sum of child masses, com = sum(child com * child mass) / total,
+            // children in ascending digit order
+            const uint32_t cf = meta.z;
+            double s[3] = {0.0, 0.0, 0.0};
+            mtot = 0.0;
+            const double2 *cc = (const double2 *)a.node_com;
+            for (uint32_t ch = cf; ch < cf + nchild; ++ch) {
+                const double2 xy = cc[3 * (size_t)ch], zm = cc[3 * (size_t)ch + 1];
+                mtot += zm.y;
+                s[0] += xy.x * zm.y;
+                s[1] += xy.y * zm.y;
+                s[2] += zm.x * zm.y;
+            }
+            for (int k = 0; k < 3; ++k)
+                c[k] = s[k] / mtot;
+            cell_record3(a, (int)(meta.w >> 8), width, open2, prune);
+        }
+        store_node3(a, u, meta, c, mtot, width, open2, prune);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_com3(Com3Args a, int d, int d_hi)
+{
+    if (d_hi > d + 1) {
+        // levels past the ones the host expects to exist (normally empty), by one block
+        for (int dd = d_hi - 1; dd >= d; --dd) {
+            if (a.level_start[dd + 1] > a.level_start[dd]) {  // uniform
+                com3_level(a, dd);
+                __threadfence_block();
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    com3_level(a, d);
+}
+
+int bh3_com(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
+{
+    Com3Args c;
+    c.node_meta = b.node_meta;
+    c.level_start = b.level_start;
+    c.idx = b.idx[0];
+    c.pos = a.pos;
+    c.mass = a.mass;
+    c.radius = a.radius;
+    c.posm_s = b.posm_s;
+    c.box = b.box;
+    c.node_com = b.node_com;
+    c.node_rec = b.node_rec;
+    c.node_aux = b.node_aux;
+    c.cut = b.cut;
+    c.leaf_sum = b.leaf_sum;
+    c.inv_len = 1.0 / a.units.len_unit;
+    c.inv_mass = 1.0 / a.units.mass_unit;
+    c.theta = a.theta;
+    c.cth = a.collision_th;
+    hipLaunchKernelGGL(k_leaf_sums3, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[0], b.idx[0], a.n, a.pos, a.mass,
+                       a.radius, c.inv_len, c.inv_mass, b.posm_s, b.rad_s, b.leaf_sum);
+    if (b.launched < BH_MAX_DEPTH - 1)
+        hipLaunchKernelGGL(k_com3, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
+    for (int d = b.launched - 1; d >= 0; --d)
+        hipLaunchKernelGGL(k_com3, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, c, d, d + 1);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------ 6 traversal + integration
+
+constexpr int TR3_BATCH = 36;   // nodes popped and visited together (at most one per lane)
+constexpr int TR3_STACK = 440;  // entries per wave
+constexpr int TR3_HIGH = TR3_STACK - 150;  // above this the wave pops one node at a time: a depth-first
+                                           // descent adds at most 7 entries per tree level (21 levels)
+constexpr float TR3_BAND = 4.0e-5f;  // float comparisons closer than this are repeated in FP64
+
+struct Force3Args {
+    const float4 *posm_s;
+    const float *rad_s;
+    const float4 *node_rec;
+    const uint4 *node_aux;
+    const double *node_com;
+    const uint32_t *idx;
+    const uint8_t *dyn;
+    const double *radius;
+    double *pos, *vel, *acc;
+    unsigned long long *counters;
+    int n;
+    ForceConsts fc;
+    IntegrateArgs ia;
+    double theta, collision_th;
+};
+
+enum { F3_NOEPS = 0, F3_EPS = 1, F3_EXACT = 2 };
+template <int MODE>
+__device__ __forceinline__ float force_scale3(float d2, float nm, float eps2, float eps3)
+{
+    if (MODE == F3_EXACT) {
+        const float r2 = d2 + eps2;
+        return nm * __builtin_amdgcn_rcpf(r2 * __builtin_sqrtf(r2) + eps3);
+    }
+    const float rinv = __builtin_amdgcn_rsqf(MODE == F3_EPS ? d2 + eps2 : d2);
+    return ((rinv * rinv) * rinv) * nm;
+}
+
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
+{
+    __shared__ uint32_t st_node[4][TR3_STACK];
+    __shared__ uint64_t st_mask[4][TR3_STACK];
+    // the batch being visited: per entry {record}, {lane mask, opening threshold, child word}
+    __shared__ __attribute__((aligned(16))) uint4 st_batch[4][TR3_BATCH][2];
+    __shared__ float st_prune[4][TR3_BATCH];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    uint32_t *snode = st_node[w];
+    uint64_t *smask = st_mask[w];
+    uint4(*batch)[2] = st_batch[w];
+    float *bprune = st_prune[w];
+
+    const int k = (blockIdx.x * 4 + w) * 64 + lane;
+    if ((blockIdx.x * 4 + w) * 64 >= a.n)
+        return;  // whole wave idle (no block barriers below)
+    const bool valid = k < a.n;
+    const int ks = valid ? k : a.n - 1;
+    const uint32_t body = a.idx[ks];
+    const float4 me = a.posm_s[ks];
+    const float xi = me.x, yi = me.y, zi = me.z, ri = a.rad_s[ks];
+    const bool dynamic = valid && a.dyn[body];
+    // BarnesHut::isCollide(Body, Vector): 2 r_i + th > dist drops an accepted cell (barnesHut.cpp:131-134)
+    const float thn = 2.f * ri + a.fc.cth;
+    const float thn2 = thn * thn, thn2_band = thn2 * TR3_BAND;
+    const bool self_test = !(a.fc.cth > 0.f);
+    const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
+    const double pdx = a.pos[3 * (size_t)body], pdy = a.pos[3 * (size_t)body + 1], pdz = a.pos[3 * (size_t)body + 2];
+    const double rd = a.radius[body];
+    // bounding box of the wave's targets and their largest cell cutoff (see k_bh_force)
+    float g0[3] = {xi, yi, zi}, g1[3] = {xi, yi, zi}, safe2 = thn2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            g0[d] = fminf(g0[d], __shfl_xor(g0[d], o));
+            g1[d] = fmaxf(g1[d], __shfl_xor(g1[d], o));
+        }
+        safe2 = fmaxf(safe2, __shfl_xor(safe2, o));
+    }
+    safe2 *= 1.001f;
+
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    unsigned long long n_eval = 0, n_acc = 0, n_recheck = 0, n_visit = 0, n_batch = 0;
+    int max_top = 0;
+
+    int top = 0;
+    {
+        const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
+        if (m0 != 0ull) {
+            if (lane == 0) {
+                snode[0] = 0u;
+                smask[0] = m0;
+            }
+            top = 1;
+        }
+    }
+    while (top > 0) {
+        if (STATS) {
+            n_batch += 1;
+            max_top = top > max_top ? top : max_top;
+        }
+        int c = top < TR3_BATCH ? top : TR3_BATCH;
+        int room = (TR3_HIGH - top) / 7;
+        if (room < 1)
+            room = 1;
+        if (c > room)
+            c = room;
+        const int base = top - c;
+        uint32_t u = 0;
+        uint64_t um = 0ull;
+        if (lane < c) {
+            u = snode[base + lane];
+            um = smask[base + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint4 aux = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < c) {
+            rec = a.node_rec[u];
+            aux = a.node_aux[u];
+        }
+        top = base;
+        const float nw = __uint_as_float(aux.x);
+        // Each popped node is first judged for the wave as a whole by the distance of its centre of
+        // mass to the bounding box of the wave's targets: opened by every lane -> its children go
+        // onto the stack right here; accepted by every lane -> force only; far from every lane ->
+        // no cutoff and prune tests; the rest and the bodies take the full tests.
+        const uint64_t cmask = c >= 64 ? ~0ull : ((1ull << c) - 1ull);
+        const float ex = fmaxf(fmaxf(g0[0] - rec.x, rec.x - g1[0]), 0.f), ey = fmaxf(fmaxf(g0[1] - rec.y, rec.y - g1[1]), 0.f),
+                    ez = fmaxf(fmaxf(g0[2] - rec.z, rec.z - g1[2]), 0.f);
+        const float fxm = fmaxf(rec.x - g0[0], g1[0] - rec.x), fym = fmaxf(rec.y - g0[1], g1[1] - rec.y),
+                    fzm = fmaxf(rec.z - g0[2], g1[2] - rec.z);
+        const float dmin2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
+        const float dmax2 = __builtin_fmaf(fxm, fxm, __builtin_fmaf(fym, fym, fzm * fzm));
+        const uint64_t bodym = __builtin_amdgcn_ballot_w64((int)aux.x < 0) & cmask;
+        const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~bodym;
+        const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < nw * 0.999f) & farm_all;
+        const uint64_t surem = __builtin_amdgcn_ballot_w64(dmin2 > nw * 1.001f) & farm_all;
+        const uint64_t farcm = farm_all & ~(openm | surem);
+        const uint64_t nearm = cmask & ~(bodym | farm_all);
+        if (openm != 0ull) {
+            // exclusive prefix of the child counts (1..8) of the opened nodes, from ballots of its bits
+            const uint32_t ncl = __builtin_amdgcn_inverse_ballot_w64(openm) ? (aux.y & 15u) : 0u;
+            uint32_t off = 0;
+            int total = 0;
+#pragma unroll
+            for (int bit = 0; bit < 4; ++bit) {
+                const uint64_t bb = __builtin_amdgcn_ballot_w64(((ncl >> bit) & 1u) != 0u);
+                off += mbcnt64(bb) << bit;
+                total += (int)__popcll(bb) << bit;
+            }
+            const uint32_t cf = aux.y >> 4;
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i)
+                if (i < ncl) {
+                    snode[top + off + i] = cf + i;
+                    smask[top + off + i] = um;
+                }
+            top += total;
+            if (STATS) {
+                n_visit += (unsigned long long)__popcll(openm);
+                unsigned long long e = __builtin_amdgcn_inverse_ballot_w64(openm) ? (unsigned long long)__popcll(um) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                    e += __shfl_xor(e, o);
+                n_eval += e;
+            }
+        }
+        // stage the rest in LDS by kind; every lane then reads entry j at the same address
+        const int nsure = (int)__popcll(surem), nfar = nsure + (int)__popcll(farcm), ncell = nfar + (int)__popcll(nearm);
+        const int cstaged = ncell + (int)__popcll(bodym);
+        int slot_j = (int)mbcnt64(surem);
+        slot_j = __builtin_amdgcn_inverse_ballot_w64(farcm) ? nsure + (int)mbcnt64(farcm) : slot_j;
+        slot_j = __builtin_amdgcn_inverse_ballot_w64(nearm) ? nfar + (int)mbcnt64(nearm) : slot_j;
+        slot_j = __builtin_amdgcn_inverse_ballot_w64(bodym) ? ncell + (int)mbcnt64(bodym) : slot_j;
+        const bool staged = __builtin_amdgcn_inverse_ballot_w64(cmask & ~openm);
+        if (staged) {
+            batch[slot_j][0] = make_uint4(__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z),
+                                          __float_as_uint(rec.w));
+            batch[slot_j][1] = make_uint4((uint32_t)um, (uint32_t)(um >> 32), aux.x, aux.y);
+            bprune[slot_j] = __uint_as_float(aux.z);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        // node index of batch entry j (only the rare FP64 re-decisions need it)
+        auto node_of = [&](int j) {
+            j = __builtin_amdgcn_readfirstlane(j);
+            const uint64_t at = __builtin_amdgcn_ballot_w64(staged && slot_j == j);
+            return (uint32_t)__builtin_amdgcn_readlane((int)u, (int)__builtin_ctzll(at));
+        };
+        auto dist64 = [&](const double *nc) {
+            const double qx = nc[0] - pdx, qy = nc[1] - pdy, qz = nc[2] - pdz;
+            return sqrt(qx * qx + qy * qy + qz * qz);
+        };
+        // ---- cells: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
+        auto visit_cell = [&](const int j, auto far_tag) {
+            constexpr bool FAR = decltype(far_tag)::value;
+            const uint4 r = batch[j][0], q = batch[j][1];
+            const float nm = __uint_as_float(r.w), cw = __uint_as_float(q.z);
+            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
+            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
+            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;  // lanes this node is visited for
+            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi, dz = __uint_as_float(r.z) - zi;
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const float g = d2 - cw;
+            uint64_t accm = __builtin_amdgcn_ballot_w64(g > 0.f);
+            uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= cw * TR3_BAND);
+            // an accepted cell counts only outside 2 r_i + th of its centre of mass (barnesHut.cpp:75)
+            uint64_t farm = ~0ull;
+            if (!FAR) {
+                const float g2 = d2 - thn2;
+                farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
+                ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band);
+            }
+            if ((ambm & mj) != 0ull) {
+                // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
+                const double *nc = a.node_com + 6 * (size_t)node_of(j);
+                const double dist = dist64(nc);
+                accm = __builtin_amdgcn_ballot_w64(nc[4] / dist < a.theta);
+                if (!FAR)
+                    farm = __builtin_amdgcn_ballot_w64(!(rd * 2 + a.collision_th > dist));
+                if (STATS)
+                    n_recheck += 1;
+            }
+            const uint64_t macc = mj & accm;
+            const uint64_t okm = FAR ? macc : macc & farm;
+            // a lane that sees the cell wholly inside its cutoff distance does not open it
+            uint64_t om = mj ^ macc;
+            if (!FAR)
+                om &= ~__builtin_amdgcn_ballot_w64(d2 < bprune[j]);
+            if (om != 0ull) {
+                const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w);
+                const int cf = (int)(packed >> 4), nc = (int)(packed & 15u);
+                if (lane < nc) {
+                    snode[top + lane] = (uint32_t)(cf + lane);
+                    smask[top + lane] = om;
+                }
+                top += nc;
+            }
+            if (okm != 0ull) {
+                asm volatile("" ::: "memory");  // keep the force arithmetic inside this branch
+                const float sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? force_scale3<MODE>(d2, nm, eps2, eps3) : 0.f;
+                fx = __builtin_fmaf(dx, sc, fx);
+                fy = __builtin_fmaf(dy, sc, fy);
+                fz = __builtin_fmaf(dz, sc, fz);
+            }
+            if (STATS) {
+                n_eval += (unsigned long long)__popcll(mj);
+                n_acc += (unsigned long long)__popcll(okm);
+                n_visit += 1;
+            }
+        };
+        // ---- cells every lane accepts: only the force, for the lanes the cell is visited for ----
+        for (int j = 0; j < nsure; ++j) {
+            const uint4 r = batch[j][0];
+            const uint2 q = *(const uint2 *)&batch[j][1];
+            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
+            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
+            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
+            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi, dz = __uint_as_float(r.z) - zi;
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const float sc = __builtin_amdgcn_inverse_ballot_w64(mj) ? force_scale3<MODE>(d2, __uint_as_float(r.w), eps2, eps3) : 0.f;
+            fx = __builtin_fmaf(dx, sc, fx);
+            fy = __builtin_fmaf(dy, sc, fy);
+            fz = __builtin_fmaf(dz, sc, fz);
+            if (STATS) {
+                n_eval += (unsigned long long)__popcll(mj);
+                n_acc += (unsigned long long)__popcll(mj);
+                n_visit += 1;
+            }
+        }
+        for (int j = nsure; j < nfar; ++j)
+            visit_cell(j, std::true_type{});
+        for (int j = nfar; j < ncell; ++j)
+            visit_cell(j, std::false_type{});
+        // ---- bodies: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
+        for (int j = ncell; j < cstaged; ++j) {
+            const uint4 r = batch[j][0], q = batch[j][1];
+            const float nm = __uint_as_float(r.w), bw = __uint_as_float(q.z);  // bw = -(r_j + th)
+            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
+            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
+            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
+            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi, dz = __uint_as_float(r.z) - zi;
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const float th = ri - bw;
+            const float t2 = th * th;
+            const float g = d2 - t2;
+            uint64_t passm = __builtin_amdgcn_ballot_w64(g >= 0.f);
+            const uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= t2 * TR3_BAND) & mj;
+            if (ambm != 0ull) {
+                const double *nc = a.node_com + 6 * (size_t)node_of(j);
+                const double dist = dist64(nc);
+                passm = __builtin_amdgcn_ballot_w64(!(rd + (-nc[4]) + a.collision_th > dist));
+                if (STATS)
+                    n_recheck += 1;
+            }
+            uint64_t okm = mj & passm;
+            if (self_test)  // the body itself has d2 == 0 (the reference skips it by pointer)
+                okm &= __builtin_amdgcn_ballot_w64(d2 > 0.f);
+            if (okm != 0ull) {
+                asm volatile("" ::: "memory");
+                const float sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? force_scale3<MODE>(d2, nm, eps2, eps3) : 0.f;
+                fx = __builtin_fmaf(dx, sc, fx);
+                fy = __builtin_fmaf(dy, sc, fy);
+                fz = __builtin_fmaf(dz, sc, fz);
+            }
+            if (STATS) {
+                n_eval += (unsigned long long)__popcll(mj);
+                n_acc += (unsigned long long)__popcll(okm);
+                n_visit += 1;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        sx += (double)fx;
+        sy += (double)fy;
+        sz += (double)fz;
+    }
+
+    if (STATS && lane == 0) {
+        atomicAdd(&a.counters[0], n_eval);
+        atomicAdd(&a.counters[1], n_acc);
+        atomicAdd(&a.counters[4], n_recheck);
+        atomicAdd(&a.counters[5], n_visit);
+        atomicAdd(&a.counters[6], n_batch);
+        atomicMax(&a.counters[7], (unsigned long long)max_top);
+    }
+    if (!valid)
+        return;
+    double acc[3] = {0.0, 0.0, 0.0};
+    double *ap = a.acc + 3 * (size_t)body;
+    if (dynamic) {
+        acc[0] = sx * a.ia.acc_factor;
+        acc[1] = sy * a.ia.acc_factor;
+        acc[2] = sz * a.ia.acc_factor;
+        for (int d = 0; d < 3; ++d)
+            ap[d] = acc[d];
+    } else {
+        // a static body keeps the acceleration it was given (barnesHut.cpp:96-106)
+        for (int d = 0; d < 3; ++d)
+            acc[d] = ap[d];
+    }
+    // every body is advanced with its own velocity (barnesHut.cpp:108-123)
+    if (a.ia.do_integrate) {
+        const double p0[3] = {pdx, pdy, pdz};
+        for (int d = 0; d < 3; ++d) {
+            const double v = a.vel[3 * (size_t)body + d] + acc[d] * a.ia.dt_kick;
+            a.vel[3 * (size_t)body + d] = v;
+            a.pos[3 * (size_t)body + d] = p0[d] + v * a.ia.dt;
+        }
+    }
+}
+
+int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
+{
+    Force3Args f;
+    f.posm_s = b.posm_s;
+    f.rad_s = b.rad_s;
+    f.node_rec = b.node_rec;
+    f.node_aux = b.node_aux;
+    f.node_com = b.node_com;
+    f.idx = b.idx[0];
+    f.dyn = a.dyn;
+    f.radius = a.radius;
+    f.pos = a.pos;
+    f.vel = a.vel;
+    f.acc = a.acc;
+    f.counters = b.counters;
+    f.n = a.n;
+    f.fc = a.fc;
+    f.ia = a.ia;
+    f.theta = a.theta;
+    f.collision_th = a.collision_th;
+    const int waves = (a.n + 63) / 64;
+    const dim3 grid((waves + 3) / 4);
+    const int mode = a.fc.exact_denom ? F3_EXACT : (a.fc.eps2_negligible ? F3_NOEPS : F3_EPS);
+    if (a.collect_stats) {
+        if (mode == F3_EXACT)
+            hipLaunchKernelGGL((k_bh3_force<F3_EXACT, true>), grid, dim3(256), 0, s, f);
+        else if (mode == F3_EPS)
+            hipLaunchKernelGGL((k_bh3_force<F3_EPS, true>), grid, dim3(256), 0, s, f);
+        else
+            hipLaunchKernelGGL((k_bh3_force<F3_NOEPS, true>), grid, dim3(256), 0, s, f);
+    } else {
+        if (mode == F3_EXACT)
+            hipLaunchKernelGGL((k_bh3_force<F3_EXACT, false>), grid, dim3(256), 0, s, f);
+        else if (mode == F3_EPS)
+            hipLaunchKernelGGL((k_bh3_force<F3_EPS, false>), grid, dim3(256), 0, s, f);
+        else
+            hipLaunchKernelGGL((k_bh3_force<F3_NOEPS, false>), grid, dim3(256), 0, s, f);
+    }
+    NB_HIP(hipGetLastError());
+    return bh_finish(s, b.level_start, b.counters, b.levels_host);
+}
+
+// ------------------------------------------------------------------ buffers
+
+template <typename T>
+static int dev_alloc3(T *&p, size_t count)
+{
+    void *v = nullptr;
+    hipError_t e = hipMalloc(&v, count * sizeof(T) + 256);
+    if (e != hipSuccess)
+        return fail(NB_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    p = (T *)v;
+    return NB_OK;
+}
+
+int bh3_alloc(Bh3Buffers &b, int n)
+{
+    b.n = n;
+    b.node_cap = 2 * (size_t)n + 8;
+    NB_TRY(dev_alloc3(b.box, 6));
+    NB_TRY(dev_alloc3(b.cut, 4));
+    NB_TRY(dev_alloc3(b.bbox_part, 6 * BBOX3_BLOCKS));
+    for (int k = 0; k < 2; ++k) {
+        NB_TRY(dev_alloc3(b.keys[k], (size_t)n));
+        NB_TRY(dev_alloc3(b.idx[k], (size_t)n));
+    }
+    NB_TRY(dev_alloc3(b.hist, sort_hist_words(n)));
+    NB_TRY(dev_alloc3(b.hist_totals, 256));
+    NB_TRY(dev_alloc3(b.leaf_sum, 6 * (size_t)n));
+    NB_TRY(dev_alloc3(b.posm_s, (size_t)n));
+    NB_TRY(dev_alloc3(b.rad_s, (size_t)n));
+    NB_TRY(dev_alloc3(b.node_meta, b.node_cap));
+    {
+        uint8_t *sp = nullptr;
+        NB_TRY(dev_alloc3(sp, ((size_t)n + 256) * build_split_bytes(3)));
+        b.split = sp;
+    }
+    NB_TRY(dev_alloc3(b.level_start, BH_MAX_DEPTH + 2));
+    NB_TRY(dev_alloc3(b.bsum, BH_SCAN_BLOCKS));
+    NB_TRY(dev_alloc3(b.node_com, 6 * b.node_cap));
+    NB_TRY(dev_alloc3(b.node_rec, b.node_cap));
+    NB_TRY(dev_alloc3(b.node_aux, b.node_cap));
+    NB_TRY(dev_alloc3(b.counters, 8));
+    void *h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
+        return fail(NB_ERR_NOMEM, "hipHostMalloc failed");
+    b.levels_host = (uint32_t *)h;
+    *b.levels_host = 0u;
+    return NB_OK;
+}
+
+void bh3_free(Bh3Buffers &b)
+{
+    (void)hipFree(b.box);
+    (void)hipFree(b.cut);
+    (void)hipFree(b.bbox_part);
+    for (int k = 0; k < 2; ++k) {
+        (void)hipFree(b.keys[k]);
+        (void)hipFree(b.idx[k]);
+    }
+    (void)hipFree(b.hist);
+    (void)hipFree(b.hist_totals);
+    (void)hipFree(b.leaf_sum);
+    (void)hipFree(b.posm_s);
+    (void)hipFree(b.rad_s);
+    (void)hipFree(b.node_meta);
+    (void)hipFree(b.split);
+    (void)hipFree(b.level_start);
+    (void)hipFree(b.bsum);
+    (void)hipFree(b.node_com);
+    (void)hipFree(b.node_rec);
+    (void)hipFree(b.node_aux);
+    (void)hipFree(b.counters);
+    if (b.levels_host)
+        (void)hipHostFree(b.levels_host);
+    b = Bh3Buffers();
+}
+
+}  // namespace nb

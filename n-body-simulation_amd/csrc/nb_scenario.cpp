@@ -9,9 +9,11 @@
 //
 // Built with g++ like the reference's CPU program: the last bit of cos/sin depends on
 // whether the compiler pairs them into one sincos call, and the fixtures were made with g++.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "nb_error.h"
 #include "nbody.h"
@@ -114,4 +116,33 @@ extern "C" int nb_init_scenario(int sim, int n, unsigned seed, nb_body *out)
     default:
         return nb::fail(NB_ERR_ARG, "ERROR: simulation doesn't exist");
     }
+}
+
+// The 2-D scenario for the same seed (identical x, y and velocities), then one more rand() per
+// body in index order for its height: z = thickness (2 u - 1); bodies of the suns' mass stay in
+// the plane.  The reference's scenarios are flat; this gives its discs a thickness.
+extern "C" int nb3_init_scenario(int sim, int n, unsigned seed, double thickness, nb_body3 *out)
+{
+    if (!out)
+        return nb::fail(NB_ERR_ARG, "nb3_init_scenario: out is NULL");
+    if (n < 1)
+        return nb::fail(NB_ERR_ARG, "ERROR: need to have at least 1 body");
+    const int m = sim == NB_SIM_SOLAR ? 5 : n;
+    std::vector<nb_body> flat((size_t)std::max(m, n));
+    const int rc = nb_init_scenario(sim, n, seed, flat.data());
+    if (rc != NB_OK)
+        return rc;
+    if (sim == NB_SIM_SOLAR)
+        srand(seed);  // the solar system draws nothing itself
+    for (int i = 0; i < m; ++i) {
+        const double u = rand() / (double)RAND_MAX;
+        nb_body3 &b = out[i];
+        std::memset(&b, 0, sizeof(b));
+        b.is_dynamic = flat[i].is_dynamic;
+        b.mass = flat[i].mass;
+        b.radius = flat[i].radius;
+        b.position = {flat[i].position.x, flat[i].position.y, flat[i].mass == kSunMass ? 0.0 : thickness * (2.0 * u - 1.0)};
+        b.velocity = {flat[i].velocity.x, flat[i].velocity.y, 0.0};
+    }
+    return NB_OK;
 }

@@ -14,7 +14,7 @@ from conftest import ROOT, golden
 def header_functions():
     text = open(os.path.join(ROOT, "include", "nbody.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(nb_[a-z_0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(nb3?_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol(nb):

@@ -1,0 +1,227 @@
+"""Parity of the three-dimensional HIP paths (the nb3_ entry points, through the C ABI).
+
+The reference is two-dimensional, so the checks are of two kinds:
+  * flat input (all z = 0): the 3-D paths must agree with the reference's own golden
+    accelerations (tests/golden, made by the compiled reference) to the 2-D bars;
+  * z != 0: the 3-D paths against the CPU oracle's 3-D restatement (oracle/nbody_oracle3.c,
+    which is pinned to the reference only through the flat case -- parity unpinned beyond it).
+Bars as in 2-D: direct sum 1e-5, Barnes-Hut 1e-4 relative per body; FP64 integration.
+"""
+import numpy as np
+import pytest
+
+from conftest import bodies_from_golden, golden, rel_err
+from oracle_lib import lift3
+
+pytestmark = pytest.mark.gpu
+
+DS_TOL = 1e-5
+BH_TOL = 1e-4
+TRAJ_TOL = 1e-6
+
+
+def gpu_accel3(nb, b, alg, params=None):
+    with nb.NBodySim3(len(b), alg, params) as sim:
+        sim.set_bodies(b)
+        return sim.compute_accel()
+
+
+@pytest.mark.parametrize("name", ["solar_n5", "spiral_n256", "random_n256", "collision_n256", "spiral_n4096",
+                                  "random_n4096", "collision_n4096"])
+def test_flat_input_matches_the_reference_golden(nb, name):
+    g = golden(name)
+    b3 = lift3(bodies_from_golden(g))
+    for alg, key, tol in ((nb.DIRECT, "acc_direct", DS_TOL), (nb.BARNES_HUT, "acc_bh", BH_TOL)):
+        acc = gpu_accel3(nb, b3, alg)
+        assert not acc[:, 2].any()
+        err = rel_err(acc[:, :2], g[key])
+        assert err.max() <= tol, (name, alg, err.max())
+
+
+@pytest.mark.parametrize("sim,n,thick", [(0, 3000, 5.0e10), (1, 4096, 2.0e11), (2, 5000, 2.0e10), (1, 777, 5.0e11),
+                                         (3, 5, 3.0e10)])
+def test_direct3_matches_the_oracle(nb, oracle, sim, n, thick):
+    b = oracle.scenario3(sim, n, 4242, thickness=thick)
+    assert np.array_equal(nb.init_scenario3(sim, n, 4242, thick)["pos"], b["pos"])
+    err = rel_err(gpu_accel3(nb, b, nb.DIRECT), oracle.direct_accel3(b))
+    assert err.max() <= DS_TOL, err.max()
+
+
+@pytest.mark.parametrize("sim,n,thick", [(0, 3000, 5.0e10), (1, 4096, 2.0e11), (2, 5000, 2.0e10), (1, 777, 5.0e11),
+                                         (3, 5, 3.0e10), (2, 20000, 1.0e11)])
+def test_bh3_matches_the_oracle(nb, oracle, sim, n, thick):
+    b = oracle.scenario3(sim, n, 99, thickness=thick)
+    ref, stats = oracle.bh_accel3(b, with_stats=True)
+    with nb.NBodySim3(len(b), nb.BARNES_HUT) as s:
+        s.set_bodies(b)
+        s.set_stage_timing(False, counters=True)
+        acc = s.compute_accel()
+        counters = s.debug(nb.DBG_COUNTERS, np.uint64, 8)
+    err = rel_err(acc, ref)
+    assert err.max() <= BH_TOL, err.max()
+    # every body accepts exactly the cells the oracle accepts for it: same number of
+    # contributing interactions is not observable (pruned cells count in the oracle), but the
+    # traversal must at least have evaluated something for every dynamic body
+    assert counters[1] > 0 and counters[2] > 0
+
+
+@pytest.mark.parametrize("theta", [0.3, 0.8, 1.2])
+def test_bh3_other_opening_angles(nb, oracle, theta):
+    b = oracle.scenario3(0, 2500, 5, thickness=8.0e10)
+    ref = oracle.bh_accel3(b, oracle.params(theta=theta))
+    err = rel_err(gpu_accel3(nb, b, nb.BARNES_HUT, nb.default_params(theta=theta)), ref)
+    assert err.max() <= BH_TOL, (theta, err.max())
+
+
+def test_bh3_without_cutoff_builds_the_deep_tree(nb, oracle):
+    """collision_th = 0: no closed level, one body per leaf down to wherever the bodies separate."""
+    b = oracle.scenario3(1, 3000, 8, thickness=3.0e11)
+    po, pn = oracle.params(collision_th=0.0), nb.default_params(collision_th=0.0)
+    ref = oracle.bh_accel3(b, po)
+    with nb.NBodySim3(len(b), nb.BARNES_HUT, pn) as s:
+        s.set_bodies(b)
+        acc = s.compute_accel()
+        cut = s.debug(nb.DBG_KEY_LEVELS, np.uint32, 2)
+        child = s.debug(nb.DBG_NODE_CHILD, np.uint32, 4 * len(b) + 16).reshape(-1, 2)
+        rng = s.debug(nb.DBG_NODE_RANGE, np.uint32, 4 * len(b) + 16).reshape(-1, 2)
+    assert cut[0] == 32 and cut[1] == 20
+    leaves = child[:, 1] == 0
+    assert rng[leaves, 1].sum() == len(b) and (rng[leaves, 1] == 1).all()
+    assert child[:, 1].max() <= 8 and (child[~leaves, 1] >= 2).all()
+    assert rel_err(acc, ref).max() <= BH_TOL
+
+
+def test_octree_invariants_and_keys(nb, oracle):
+    b = oracle.scenario3(2, 6000, 17, thickness=6.0e10)
+    with nb.NBodySim3(len(b), nb.BARNES_HUT) as s:
+        s.set_bodies(b)
+        s.compute_accel()
+        box = s.debug(nb.DBG_BBOX, np.float64, 6)
+        keys = s.debug(nb.DBG_SORTED_KEYS, np.uint64, len(b))
+        idx = s.debug(nb.DBG_SORTED_IDX, np.uint32, len(b))
+        order = s.order()
+        cut = s.debug(nb.DBG_KEY_LEVELS, np.uint32, 2)
+        rng = s.debug(nb.DBG_NODE_RANGE, np.uint32, 4 * len(b) + 16).reshape(-1, 2)
+        child = s.debug(nb.DBG_NODE_CHILD, np.uint32, 4 * len(b) + 16).reshape(-1, 2)
+        com = s.debug(nb.DBG_NODE_COM, np.float64, 6 * (2 * len(b) + 8)).reshape(-1, 6)
+    assert np.array_equal(box, oracle.bh_bbox3(b))
+    # keys: the oracle's octant paths, cut to the levels the device kept, sorted stably
+    levels = int(cut[1])
+    full = oracle.morton_keys3(b, box)[order]
+    keep = np.uint64(((1 << (3 * levels)) - 1) << (62 - 3 * levels)) if levels else np.uint64(0)
+    expect = full & keep
+    perm = np.argsort(expect, kind="stable")
+    assert np.array_equal(keys, expect[perm]) and np.array_equal(idx, perm.astype(np.uint32))
+    # tree: the root holds everything, children partition their parent in order, masses add up
+    n_nodes = len(rng)
+    assert rng[0, 0] == 0 and rng[0, 1] == len(b)
+    mass = b["mass"][order][idx]
+    pos = b["pos"][order][idx]
+    for u in range(n_nodes):
+        f, c = int(rng[u, 0]), int(rng[u, 1])
+        cf, nc = int(child[u, 0]), int(child[u, 1])
+        if nc:
+            assert rng[cf, 0] == f and rng[cf:cf + nc, 1].sum() == c
+            assert (rng[cf + 1:cf + nc, 0] == rng[cf:cf + nc - 1, 0] + rng[cf:cf + nc - 1, 1]).all()
+    for u in list(range(0, min(n_nodes, 200))) + list(range(max(0, n_nodes - 200), n_nodes)):
+        f, c = int(rng[u, 0]), int(rng[u, 1])
+        m = mass[f:f + c].sum()
+        assert com[u, 3] == pytest.approx(m, rel=1e-12)
+        assert np.allclose(com[u, :3], (pos[f:f + c] * mass[f:f + c, None]).sum(0) / m, rtol=1e-9, atol=1e-3)
+
+
+@pytest.mark.parametrize("alg", [0, 1])
+def test_trajectories_follow_the_oracle(nb, oracle, alg):
+    b = oracle.scenario3(0, 1500, 21, thickness=4.0e10)
+    steps = 100
+    ref = (oracle.direct_step3 if alg == 0 else oracle.bh_step3)(b, steps)
+    with nb.NBodySim3(len(b), alg) as s:
+        s.set_bodies(b)
+        s.update(steps)
+        out = s.read_bodies()
+    dyn = b["is_dynamic"] != 0
+    # a body that passes within the cutoff of another may take the other side of a knife-edge
+    # decision after many steps; the bulk must follow closely
+    d = np.linalg.norm(out["pos"] - ref["pos"], axis=1) / 1.0e12
+    assert np.median(d[dyn]) < TRAJ_TOL and np.quantile(d[dyn], 0.99) < 1e-4
+    assert np.array_equal(out["pos"][~dyn], ref["pos"][~dyn])
+
+
+def test_leapfrog3_against_the_oracle_forces(nb, oracle):
+    """Kick-drift-kick built from the oracle's accelerations, 20 steps."""
+    b = oracle.scenario3(0, 600, 2, thickness=5.0e10)
+    dt = 25000.0
+    cur = b.copy()
+    acc = oracle.direct_accel3(cur)
+    for _ in range(20):
+        cur["vel"] += 0.5 * dt * acc
+        cur["pos"] += dt * cur["vel"]
+        acc = oracle.direct_accel3(cur)
+        cur["vel"] += 0.5 * dt * acc
+    with nb.NBodySim3(len(b), nb.DIRECT, nb.default_params(integrator=nb.LEAPFROG)) as s:
+        s.set_bodies(b)
+        s.update(20)
+        out = s.read_bodies()
+    # FP32 forces (1e-5 relative) over 20 steps move a body near the sun by a few km at most
+    assert np.abs(out["pos"] - cur["pos"]).max() / 1.0e12 < 2e-8
+    assert np.abs(out["vel"] - cur["vel"]).max() / np.abs(cur["vel"]).max() < 1e-6
+
+
+def test_rotating_the_system_rotates_the_answer(nb, oracle):
+    """A disc in the x-y plane and the same disc stood up in the y-z plane."""
+    b = oracle.scenario3(0, 4000, 31, thickness=1.0e10)
+    r = b.copy()
+    for f in ("pos", "vel"):
+        r[f][:, 0] = -b[f][:, 2]
+        r[f][:, 2] = b[f][:, 0]
+    for alg, tol in ((nb.DIRECT, 2 * DS_TOL), (nb.BARNES_HUT, None)):
+        a = gpu_accel3(nb, b, alg)
+        ar = gpu_accel3(nb, r, alg)
+        back = np.stack([ar[:, 2], ar[:, 1], -ar[:, 0]], axis=1)
+        if tol is not None:
+            assert rel_err(back, a).max() <= tol
+        else:
+            # the octree's cells differ between the two orientations (the opening test uses the
+            # x-width): each must match its own oracle, and the two agree like two theta = 0.5 trees
+            assert rel_err(ar, oracle.bh_accel3(r)).max() <= BH_TOL
+            assert np.median(rel_err(back, a)) < 2e-2
+
+
+def test_large_direct3_sampled_and_newton(nb, oracle):
+    n = 100000
+    b = oracle.scenario3(2, n, 1, thickness=5.0e10)
+    acc = gpu_accel3(nb, b, nb.DIRECT)
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(n, 40, replace=False))
+    for i in pick:
+        ref = oracle.direct_accel3(b, t0=int(i), t1=int(i) + 1)[0]
+        assert np.linalg.norm(acc[i] - ref) <= DS_TOL * np.linalg.norm(ref)
+    # Newton's third law: with every body dynamic the forces cancel
+    f = (acc * b["mass"][:, None]).sum(0)
+    scale = (np.linalg.norm(acc, axis=1) * b["mass"]).sum()
+    assert np.linalg.norm(f) / scale < 1e-6
+
+
+def test_large_bh3_against_direct3(nb, oracle):
+    n = 300000
+    b = oracle.scenario3(2, n, 3, thickness=5.0e10)
+    a_bh = gpu_accel3(nb, b, nb.BARNES_HUT)
+    a_ds = gpu_accel3(nb, b, nb.DIRECT)
+    err = rel_err(a_bh, a_ds)
+    assert np.median(err) < 2e-2 and np.quantile(err, 0.999) < 0.2
+    with nb.NBodySim3(n, nb.BARNES_HUT, nb.default_params(theta=0.2)) as s:
+        s.set_bodies(b)
+        tight = s.compute_accel()
+    assert np.median(rel_err(tight, a_ds)) < np.median(err) / 3
+
+
+def test_argument_checks(nb):
+    with pytest.raises(nb.NBodyError):
+        nb.NBodySim3(0, nb.DIRECT)
+    with pytest.raises(nb.NBodyError):
+        nb.NBodySim3(10, nb.BARNES_HUT, nb.default_params(bucket_depth=9))
+    with nb.NBodySim3(8, nb.DIRECT) as s:
+        with pytest.raises(nb.NBodyError):
+            s.update()
+        with pytest.raises(nb.NBodyError):
+            s.set_bodies(np.zeros(7, dtype=nb.BODY3_DTYPE))
