@@ -216,7 +216,9 @@ int nb_diagnostics(nb_sim *sim, double *out, int count);
  * Barnes-Hut an octree with one body per leaf whose cells are split at the midpoint of every
  * axis (z treated like y in QuadTree::getQuadrant, src/cpu/quadtree.cpp:41-72), children taken
  * in the order 4 (lower z) + 2 (lower y) + (right x), opening test cell x-width / distance <
- * theta (src/cpu/barnesHut.cpp:70-71).  For bodies that all lie in the plane z = 0 the results
+ * theta (src/cpu/barnesHut.cpp:70-71).  The root box is padded and rounded on every axis as
+ * BarnesHut::computeBoundingBox does (barnesHut.cpp:23-35); its z range is then widened to its
+ * x-width when smaller, so that the cells of a thin disc are not slabs.  For bodies that all lie in the plane z = 0 the results
  * are those of the 2-D entry points.  One GPU per simulation; nb_params.bucket_depth must be 0.
  * Each nb3_ function mirrors the nb_ function of the same name. */
 

@@ -1,7 +1,8 @@
 // nb_bh3.hip -- the Barnes-Hut pipeline of nb_bh.hip for three dimensions (see nb_dim3.h for the
 // rules it follows).  Same stages on one stream, no host synchronisation in between:
 //   1 bbox   min/max of the three coordinates, rounded to float and padded as
-//            BarnesHut::computeBoundingBox pads x and y (barnesHut.cpp:23-35)
+//            BarnesHut::computeBoundingBox pads x and y (barnesHut.cpp:23-35); the z range is
+//            widened to the x-width when it is smaller
 //   2 keys   octant paths by the FP64 midpoint descent of QuadTree::getQuadrant
 //            (quadtree.cpp:41-72) on three axes: digit = 4 (below mid z) + 2 (below mid y) +
 //            (right of mid x), 3 bits per level, at most 20 levels
@@ -98,8 +99,17 @@ __global__ __launch_bounds__(256) void k_bbox3_final(const double *part, int nbl
         box[1] = (double)(float)(m.hi[1] + margin);  // topLeft.y
         box[2] = (double)(float)(m.hi[0] + margin);  // botRight.x
         box[3] = (double)(float)(m.lo[1] - margin);  // botRight.y
-        box[4] = (double)(float)(m.hi[2] + margin);  // upper z
-        box[5] = (double)(float)(m.lo[2] - margin);  // lower z
+        double zup = (double)(float)(m.hi[2] + margin), zlo = (double)(float)(m.lo[2] - margin);
+        // The root is at least as deep in z as it is wide in x (centred on the z range): cells
+        // then are no flatter than wide, so a thin disc is not cut into slabs that the opening
+        // test, which looks at the x-width only, would all have to accept one by one.
+        if (zup - zlo < box[2] - box[0]) {
+            const double mid = (zup + zlo) / 2.0, half = (box[2] - box[0]) / 2.0;
+            zup = mid + half;
+            zlo = mid - half;
+        }
+        box[4] = zup;  // upper z
+        box[5] = zlo;  // lower z
         // First level whose cells no body ever opens: a cell is opened by a body that neither
         // accepts it (dist <= width / theta) nor sees it wholly inside its cutoff distance
         // (dist >= collision_th - diagonal); when width / theta < collision_th - diagonal no
@@ -430,8 +440,14 @@ int bh3_com(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
 
 // ------------------------------------------------------------------ 6 traversal + integration
 
-constexpr int TR3_BATCH = 36;   // nodes popped and visited together (at most one per lane)
-constexpr int TR3_STACK = 440;  // entries per wave
+#ifndef NB_TR3_STACK
+#define NB_TR3_STACK 440
+#endif
+#ifndef NB_TR3_BATCH
+#define NB_TR3_BATCH 36
+#endif
+constexpr int TR3_BATCH = NB_TR3_BATCH;  // nodes popped and visited together (at most one per lane)
+constexpr int TR3_STACK = NB_TR3_STACK;  // entries per wave
 constexpr int TR3_HIGH = TR3_STACK - 150;  // above this the wave pops one node at a time: a depth-first
                                            // descent adds at most 7 entries per tree level (21 levels)
 constexpr float TR3_BAND = 4.0e-5f;  // float comparisons closer than this are repeated in FP64

@@ -12,7 +12,9 @@
 // --dump-every K, --ppm PREFIX (one image PREFIX_<step>.ppm per dumped step, drawn by the rule
 // of the reference's storeFrame), --window W, --iters K (nBodyCPU form),
 // --integrator euler|leapfrog, --energy (prints the conserved quantities before and after the
-// run), --quiet.
+// run), --thickness T (three-dimensional run: the scenario's bodies get heights in [-T, T]; frames
+// are then "NBDUMP3" records {x, y, z, vx, vy, vz, mass} and images are the x-y projection),
+// --quiet.
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -40,6 +42,26 @@ void dump_frame(std::FILE *f, const nb_body *b, int n, int step)
         rec[5 * (size_t)i + 2] = b[i].velocity.x;
         rec[5 * (size_t)i + 3] = b[i].velocity.y;
         rec[5 * (size_t)i + 4] = b[i].mass;
+    }
+    std::fwrite(rec.data(), sizeof(double), rec.size(), f);
+}
+
+void dump_frame3(std::FILE *f, const nb_body3 *b, int n, int step)
+{
+    const char magic[8] = {'N', 'B', 'D', 'U', 'M', 'P', '3', 0};
+    const uint64_t hdr[2] = {(uint64_t)n, (uint64_t)step};
+    std::fwrite(magic, 1, 8, f);
+    std::fwrite(hdr, sizeof(uint64_t), 2, f);
+    std::vector<double> rec(7 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        double *r = &rec[7 * (size_t)i];
+        r[0] = b[i].position.x;
+        r[1] = b[i].position.y;
+        r[2] = b[i].position.z;
+        r[3] = b[i].velocity.x;
+        r[4] = b[i].velocity.y;
+        r[5] = b[i].velocity.z;
+        r[6] = b[i].mass;
     }
     std::fwrite(rec.data(), sizeof(double), rec.size(), f);
 }
@@ -111,6 +133,7 @@ int main(int argc, char **argv)
     std::string dump, ppm;
     int dump_every = 1, iters_flag = 300, window = 2048;
     bool quiet = false, energy = false;
+    double thickness = -1;  // >= 0: three-dimensional run
     int integrator = NB_INT_EULER;
     std::vector<const char *> pos;
     for (int i = 1; i < argc; ++i) {
@@ -144,6 +167,8 @@ int main(int argc, char **argv)
             integrator = v == "leapfrog" ? NB_INT_LEAPFROG : NB_INT_EULER;
         } else if (a == "--energy")
             energy = true;
+        else if (a == "--thickness")
+            thickness = std::atof(next("--thickness"));
         else if (a == "--quiet")
             quiet = true;
         else
@@ -180,8 +205,6 @@ int main(int argc, char **argv)
     if (dump_every < 1)
         dump_every = 1;
 
-    nbody::NBodySim nb(nBodies, alg, &params, seed);
-    nb.setup(scenario);
     std::FILE *f = nullptr;
     if (!dump.empty()) {
         f = std::fopen(dump.c_str(), "wb");
@@ -190,6 +213,41 @@ int main(int argc, char **argv)
             return EXIT_FAILURE;
         }
     }
+    if (thickness >= 0) {
+        // the same loop over the three-dimensional object
+        nbody::NBodySim3 nb3(nBodies, alg, &params, seed);
+        nb3.setup(scenario, thickness);
+        std::vector<nb_body> flat;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters; ++i) {
+            nb3.update();
+            if ((f || !ppm.empty()) && ((i + 1) % dump_every == 0 || i + 1 == iters)) {
+                nb3.readDeviceBodies();
+                if (f)
+                    dump_frame3(f, nb3.getBodies(), nBodies, i + 1);
+                if (!ppm.empty()) {
+                    flat.assign(nBodies, nb_body{});
+                    for (int k = 0; k < nBodies; ++k) {
+                        flat[k].mass = nb3.getBodies()[k].mass;
+                        flat[k].position = {nb3.getBodies()[k].position.x, nb3.getBodies()[k].position.y};
+                    }
+                    char name[32];
+                    std::snprintf(name, sizeof(name), "_%06d.ppm", i + 1);
+                    write_ppm(ppm + name, flat.data(), nBodies, window < 16 ? 16 : window);
+                }
+            }
+        }
+        nb3.sync();
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (f)
+            std::fclose(f);
+        if (!quiet)
+            std::cout << (alg == NB_ALG_DIRECT ? "direct sum" : "Barnes-Hut") << " 3-D N=" << nBodies << " sim=" << sim
+                      << " iters=" << iters << " : " << ms / iters << " ms/step" << std::endl;
+        return 0;
+    }
+    nbody::NBodySim nb(nBodies, alg, &params, seed);
+    nb.setup(scenario);
     auto print_energy = [&](const char *when) {
         double d[8];
         nb.diagnostics(d);

@@ -54,4 +54,30 @@ private:
     std::vector<nb_body> bodies_;
 };
 
+// The same object for three-dimensional bodies (the nb3_ entry points).
+class NBodySim3 {
+public:
+    NBodySim3(int n, int alg, const nb_params *params = nullptr, unsigned seed = 12345) : n_(n), seed_(seed), bodies_(n)
+    {
+        check(nb3_create(params, n, alg, &sim_), "nb3_create");
+    }
+    ~NBodySim3() { nb3_destroy(sim_); }
+    NBodySim3(const NBodySim3 &) = delete;
+    NBodySim3 &operator=(const NBodySim3 &) = delete;
+
+    void setup(int sim, double thickness) { check(nb3_setup(sim_, sim, seed_, thickness), "nb3_setup"); }
+    void setBodies(const nb_body3 *b) { check(nb3_set_bodies(sim_, b, n_), "nb3_set_bodies"); }
+    void update(int steps = 1) { check(nb3_step(sim_, steps), "nb3_step"); }
+    void readDeviceBodies() { check(nb3_read_bodies(sim_, bodies_.data()), "nb3_read_bodies"); }
+    nb_body3 *getBodies() { return bodies_.data(); }
+    void sync() { check(nb3_sync(sim_), "nb3_sync"); }
+    int size() const { return n_; }
+
+private:
+    int n_;
+    unsigned seed_;
+    nb_sim3 *sim_ = nullptr;
+    std::vector<nb_body3> bodies_;
+};
+
 }  // namespace nbody

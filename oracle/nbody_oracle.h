@@ -93,7 +93,8 @@ typedef struct orc3_body {
 int orc3_init_scenario(int sim, int n, unsigned seed, double thickness, orc3_body *out);
 void orc3_direct_accel(const orc_params *p, int n, const orc3_body *b, int t0, int t1, double *acc);
 void orc3_direct_step(const orc_params *p, int n, orc3_body *b, int nsteps);
-/* box: tl.x, tl.y, br.x, br.y as in orc_bh_bbox, then the upper and the lower z bound. */
+/* box: tl.x, tl.y, br.x, br.y as in orc_bh_bbox, then the upper and the lower z bound: padded and
+ * rounded like y, then widened about its middle to the x-width if it is smaller. */
 void orc3_bh_bbox(const orc_params *p, int n, const orc3_body *b, double *box);
 /* stats as orc_bh_accel; acc = 3 doubles per body. */
 int orc3_bh_accel(const orc_params *p, int n, const orc3_body *b, double *acc, double *stats);

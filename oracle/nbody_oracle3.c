@@ -123,6 +123,15 @@ void orc3_bh_bbox(const orc_params *p, int n, const orc3_body *b, double *box)
     box[1] = tly;
     box[2] = brx;
     box[3] = bry;
+    /* The root is at least as deep in z as it is wide in x (centred on the z range): cells then
+     * are no flatter than wide, so a thin disc is not cut into slabs that the opening test, which
+     * looks at the x-width only, would all have to accept one by one.  Flat input stays on one
+     * side of every z split either way. */
+    if (zup - zlo < brx - tlx) {
+        double mid = (zup + zlo) / 2.0, half = (brx - tlx) / 2.0;
+        zup = mid + half;
+        zlo = mid - half;
+    }
     box[4] = zup;
     box[5] = zlo;
 }

@@ -114,3 +114,36 @@ def test_ppm_frames_follow_the_reference_drawing_rule(nb, tmp_path):
     far_from_sun = inside & np.all(np.abs(px[:, None, :] - px[suns][None, :, :]).max(axis=2) > 6, axis=1)
     for x, y in px[far_from_sun][:50]:
         assert tuple(img[y, x]) == (255, 255, 255)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,alg", [("BarnesHut", 1), ("DirectSum", 0)])
+def test_thickness_runs_the_3d_path(nb, tmp_path, prog, alg):
+    """--thickness T: the same loop over the three-dimensional object, NBDUMP3 frames."""
+    n, iters, thick = 500, 4, 4.0e10
+    dump = tmp_path / "frames3.bin"
+    r = subprocess.run([binary(prog), str(n), "0", str(iters), "--seed", "9", "--thickness", str(thick), "--dump",
+                        str(dump), "--dump-every", "2", "--ppm", str(tmp_path / "f"), "--window", "128"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "3-D" in r.stdout
+    frames = []
+    with open(dump, "rb") as f:
+        while True:
+            magic = f.read(8)
+            if not magic:
+                break
+            assert magic == b"NBDUMP3\0"
+            m, step = struct.unpack("<QQ", f.read(16))
+            frames.append((step, np.frombuffer(f.read(56 * m), dtype="<f8").reshape(m, 7)))
+    assert [s for s, _ in frames] == [2, 4]
+    with nb.NBodySim3(n, alg) as sim_:
+        sim_.setup(0, 9, thick)
+        for step, frame in frames:
+            sim_.update(2)
+            b = sim_.read_bodies()
+            assert np.array_equal(frame[:, 0:3], b["pos"])
+            assert np.array_equal(frame[:, 3:6], b["vel"])
+            assert np.array_equal(frame[:, 6], b["mass"])
+    assert np.abs(frames[-1][1][:-1, 2]).max() > 1.0e10  # the bodies do have heights
+    assert (tmp_path / "f_000004.ppm").exists()

@@ -22,8 +22,9 @@ def test_flat_input_reproduces_the_2d_oracle_bit_for_bit(oracle, sim, n):
     assert np.array_equal(a3[:, :2], a2) and not a3[:, 2].any()
     box2, box3 = oracle.bh_bbox(b2), oracle.bh_bbox3(b3)
     assert np.array_equal(box3[:4], box2)
-    margin = np.float32(1.0e10)
-    assert box3[4] == margin and box3[5] == -margin
+    # the z range (+-1e10 round z = 0) is widened to the root's x-width
+    half = (box3[2] - box3[0]) / 2.0
+    assert box3[4] == half and box3[5] == -half
     t2, s2 = oracle.bh_accel(b2, with_stats=True)
     t3, s3 = oracle.bh_accel3(b3, with_stats=True)
     assert np.array_equal(t3[:, :2], t2) and not t3[:, 2].any()
