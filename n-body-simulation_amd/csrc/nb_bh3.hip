@@ -440,16 +440,22 @@ int bh3_com(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
 
 // ------------------------------------------------------------------ 6 traversal + integration
 
-#ifndef NB_TR3_STACK
-#define NB_TR3_STACK 440
+// The stack holds one entry per opened node: {first child << 4 | child count, mask of the lanes
+// that opened it}; the (up to 8) siblings share the mask.  A round pops as many entries as
+// together hold at most TR3_BATCH nodes and visits those nodes; every visited node pushes at most
+// one entry.  Above TR3_HIGH entries the wave pops one entry per round: a depth-first descent
+// then adds at most 7 entries per tree level (21 levels), on top of what the last full round
+// pushed, so TR3_STACK - TR3_HIGH >= TR3_BATCH + 7 * 21 rules out an overflow.
+#ifndef NB_TR3_HIGH
+#define NB_TR3_HIGH 64
 #endif
 #ifndef NB_TR3_BATCH
-#define NB_TR3_BATCH 36
+#define NB_TR3_BATCH 48
 #endif
-constexpr int TR3_BATCH = NB_TR3_BATCH;  // nodes popped and visited together (at most one per lane)
-constexpr int TR3_STACK = NB_TR3_STACK;  // entries per wave
-constexpr int TR3_HIGH = TR3_STACK - 150;  // above this the wave pops one node at a time: a depth-first
-                                           // descent adds at most 7 entries per tree level (21 levels)
+constexpr int TR3_BATCH = NB_TR3_BATCH;  // nodes visited together (at most one per lane)
+constexpr int TR3_HIGH = NB_TR3_HIGH;
+constexpr int TR3_STACK = TR3_HIGH + TR3_BATCH + 7 * 21 + 1;  // entries per wave
+static_assert(TR3_BATCH >= 8 && TR3_BATCH <= 64, "a round visits at most one node per lane and at least one entry");
 constexpr float TR3_BAND = 4.0e-5f;  // float comparisons closer than this are repeated in FP64
 
 struct Force3Args {
@@ -491,12 +497,14 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
 {
     __shared__ uint32_t st_node[4][TR3_STACK];
     __shared__ uint64_t st_mask[4][TR3_STACK];
+    __shared__ uint32_t st_owner[4][64];  // per batch slot: popped entry << 4 | sibling number
     // the batch being visited: per entry {record}, {lane mask, opening threshold, child word}
     __shared__ __attribute__((aligned(16))) uint4 st_batch[4][TR3_BATCH][2];
     __shared__ float st_prune[4][TR3_BATCH];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     uint32_t *snode = st_node[w];
     uint64_t *smask = st_mask[w];
+    uint32_t *owner = st_owner[w];
     uint4(*batch)[2] = st_batch[w];
     float *bprune = st_prune[w];
 
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
         const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
         if (m0 != 0ull) {
             if (lane == 0) {
-                snode[0] = 0u;
+                snode[0] = 1u;  // the root as a group of one
                 smask[0] = m0;
             }
             top = 1;
@@ -549,19 +557,43 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
             n_batch += 1;
             max_top = top > max_top ? top : max_top;
         }
-        int c = top < TR3_BATCH ? top : TR3_BATCH;
-        int room = (TR3_HIGH - top) / 7;
-        if (room < 1)
-            room = 1;
-        if (c > room)
-            c = room;
-        const int base = top - c;
+        // Pop: lane e looks at the e-th entry from the top; the entries taken are the longest run
+        // from the top whose child counts add up to at most TR3_BATCH.
+        const int avail = top < 64 ? top : 64;
+        uint32_t ew = 0;
+        if (lane < avail)
+            ew = snode[top - 1 - lane];
+        const uint32_t cnt = ew & 15u;  // 0 beyond the stack
+        uint32_t excl = 0;
+        uint64_t plane[4];
+#pragma unroll
+        for (int bit = 0; bit < 4; ++bit) {
+            plane[bit] = __builtin_amdgcn_ballot_w64(((cnt >> bit) & 1u) != 0u);
+            excl += mbcnt64(plane[bit]) << bit;
+        }
+        uint64_t takem = __builtin_amdgcn_ballot_w64(lane < avail && excl + cnt <= (uint32_t)TR3_BATCH);
+        if (top > TR3_HIGH)
+            takem = 1ull;
+        int c = 0;
+#pragma unroll
+        for (int bit = 0; bit < 4; ++bit)
+            c += (int)__popcll(plane[bit] & takem) << bit;
+        if (__builtin_amdgcn_inverse_ballot_w64(takem)) {
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i)
+                if (i < cnt)
+                    owner[excl + i] = ((uint32_t)lane << 4) | i;
+        }
+        __builtin_amdgcn_wave_barrier();
         uint32_t u = 0;
         uint64_t um = 0ull;
         if (lane < c) {
-            u = snode[base + lane];
-            um = smask[base + lane];
+            const uint32_t o = owner[lane];
+            const int at = top - 1 - (int)(o >> 4);
+            u = (snode[at] >> 4) + (o & 15u);
+            um = smask[at];
         }
+        const int base = top - (int)__popcll(takem);
         __builtin_amdgcn_wave_barrier();
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         uint4 aux = make_uint4(0u, 0u, 0u, 0u);
@@ -589,24 +621,14 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
         const uint64_t farcm = farm_all & ~(openm | surem);
         const uint64_t nearm = cmask & ~(bodym | farm_all);
         if (openm != 0ull) {
-            // exclusive prefix of the child counts (1..8) of the opened nodes, from ballots of its bits
-            const uint32_t ncl = __builtin_amdgcn_inverse_ballot_w64(openm) ? (aux.y & 15u) : 0u;
-            uint32_t off = 0;
-            int total = 0;
-#pragma unroll
-            for (int bit = 0; bit < 4; ++bit) {
-                const uint64_t bb = __builtin_amdgcn_ballot_w64(((ncl >> bit) & 1u) != 0u);
-                off += mbcnt64(bb) << bit;
-                total += (int)__popcll(bb) << bit;
+            // one entry per opened node that has children
+            const uint64_t pushm = openm & __builtin_amdgcn_ballot_w64((aux.y & 15u) != 0u);
+            if (__builtin_amdgcn_inverse_ballot_w64(pushm)) {
+                const int at = top + (int)mbcnt64(pushm);
+                snode[at] = aux.y;
+                smask[at] = um;
             }
-            const uint32_t cf = aux.y >> 4;
-#pragma unroll
-            for (uint32_t i = 0; i < 8u; ++i)
-                if (i < ncl) {
-                    snode[top + off + i] = cf + i;
-                    smask[top + off + i] = um;
-                }
-            top += total;
+            top += (int)__popcll(pushm);
             if (STATS) {
                 n_visit += (unsigned long long)__popcll(openm);
                 unsigned long long e = __builtin_amdgcn_inverse_ballot_w64(openm) ? (unsigned long long)__popcll(um) : 0ull;
@@ -680,12 +702,13 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
                 om &= ~__builtin_amdgcn_ballot_w64(d2 < bprune[j]);
             if (om != 0ull) {
                 const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w);
-                const int cf = (int)(packed >> 4), nc = (int)(packed & 15u);
-                if (lane < nc) {
-                    snode[top + lane] = (uint32_t)(cf + lane);
-                    smask[top + lane] = om;
+                if ((packed & 15u) != 0u) {
+                    if (lane == 0) {
+                        snode[top] = packed;
+                        smask[top] = om;
+                    }
+                    top += 1;
                 }
-                top += nc;
             }
             if (okm != 0ull) {
                 asm volatile("" ::: "memory");  // keep the force arithmetic inside this branch
