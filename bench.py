@@ -9,7 +9,7 @@ quotes 1509 ms/iteration for it on an unnamed NVIDIA GPU.  A "step" is one full 
 bodies: bounding box, keys, sort, tree build, centre of mass, traversal + integration.  Bodies
 are resident in HBM before the timed region.  The second half of the metric, direct-sum
 G interactions/s, is measured in the same run (N = 65,536 and N = 1,000,000) and reported in
-"direct_sum".
+"direct_sum".  "three_d" holds the same two measurements for three-dimensional bodies.
 
 With N > 1 the driver starts one rank per GPU (torch.distributed.run); every rank holds all
 bodies, integrates its slice and all-gathers positions over RCCL each step (strong scaling:
@@ -96,6 +96,44 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
         step()  # keep the ranks' collectives matched with rank 0's extra step
     sim.close()
     return dt, stages, counters
+
+
+def three_d_leg(nb, bh_n, direct_n, steps, warmup):
+    """The same two measurements for three-dimensional bodies (the nb3_ entry points; one GPU): the
+    collision discs with a half-thickness of 2e10 m, and the spiral disc for the direct sum."""
+    out = {"thickness_m": 2.0e10,
+           "note": "the reference is two-dimensional: no published number and no reference run exists for these"}
+    b = nb.init_scenario3(nb.COLLISION, bh_n, 12345, 2.0e10)
+    with nb.NBodySim3(bh_n, nb.BARNES_HUT) as sim:
+        sim.set_bodies(b)
+        sim.update(warmup)
+        sim.set_stage_timing(True, counters=False)
+        torch.cuda.synchronize()
+        sim.sync()
+        t0 = time.perf_counter()
+        sim.update(steps)
+        sim.sync()
+        dt = time.perf_counter() - t0
+        stages = sim.stage_ms()
+        sim.set_stage_timing(False, counters=True)
+        sim.update(1)
+        c = sim.debug(nb.DBG_COUNTERS, np.uint64, 8)
+    out["barnes_hut"] = {"n": bh_n, "scenario": "collision", "ms_per_step": dt * 1e3 / steps, "stage_ms": stages,
+                         "tree": {"node_evaluations": int(c[0]), "accepted_interactions": int(c[1]), "nodes": int(c[2]),
+                                  "levels": int(c[3]), "group_node_visits": int(c[5]), "batches": int(c[6])}}
+    del b
+    b = nb.init_scenario3(nb.SPIRAL, direct_n, 12345, 2.0e10)
+    with nb.NBodySim3(direct_n, nb.DIRECT) as sim:
+        sim.set_bodies(b)
+        sim.update(1)
+        sim.sync()
+        t0 = time.perf_counter()
+        sim.update(3)
+        sim.sync()
+        dt = time.perf_counter() - t0
+    out["direct_sum"] = {"n": direct_n, "scenario": "spiral", "ms_per_step": dt * 1e3 / 3,
+                         "ginteractions_per_s": float(direct_n) * direct_n * 3 / dt / 1e9}
+    return out
 
 
 def cpu_baseline(nb, bh_n):
@@ -249,6 +287,8 @@ def main():
         "roofline": roofline,
         "direct_sum": direct,
     }
+    if world == 1 and not args.no_direct:
+        out["three_d"] = three_d_leg(nb, args.bh_n, args.direct_n, args.steps, args.warmup)
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(nb, args.bh_n)
     print(json.dumps(out))
