@@ -441,21 +441,24 @@ int bh3_com(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
 // ------------------------------------------------------------------ 6 traversal + integration
 
 // The stack holds one entry per opened node: {first child << 4 | child count, mask of the lanes
-// that opened it}; the (up to 8) siblings share the mask.  A round pops as many entries as
-// together hold at most TR3_BATCH nodes and visits those nodes; every visited node pushes at most
-// one entry.  Above TR3_HIGH entries the wave pops one entry per round: a depth-first descent
-// then adds at most 7 entries per tree level (21 levels), on top of what the last full round
-// pushed, so TR3_STACK - TR3_HIGH >= TR3_BATCH + 7 * 21 rules out an overflow.
+// that opened it}; the (up to 8) siblings share the mask.  A round pops up to TR3_ENTRIES entries
+// and gives each a group of 8 lanes: lane 8 e + i takes sibling i of the e-th entry from the top
+// (lanes past the entry's child count sit the round out), so no prefix sums are needed to
+// spread the nodes over the lanes.  Every visited node pushes at most one entry.  Above TR3_HIGH
+// entries the wave pops one entry per round: a depth-first descent then adds at most 7 entries
+// per tree level (21 levels), on top of what the last full round pushed, so
+// TR3_STACK - TR3_HIGH >= 8 TR3_ENTRIES + 7 * 21 rules out an overflow.
 #ifndef NB_TR3_HIGH
 #define NB_TR3_HIGH 64
 #endif
-#ifndef NB_TR3_BATCH
-#define NB_TR3_BATCH 48
+#ifndef NB_TR3_ENTRIES
+#define NB_TR3_ENTRIES 6
 #endif
-constexpr int TR3_BATCH = NB_TR3_BATCH;  // nodes visited together (at most one per lane)
+constexpr int TR3_ENTRIES = NB_TR3_ENTRIES;
+constexpr int TR3_BATCH = 8 * TR3_ENTRIES;  // most nodes a round can hold
 constexpr int TR3_HIGH = NB_TR3_HIGH;
 constexpr int TR3_STACK = TR3_HIGH + TR3_BATCH + 7 * 21 + 1;  // entries per wave
-static_assert(TR3_BATCH >= 8 && TR3_BATCH <= 64, "a round visits at most one node per lane and at least one entry");
+static_assert(TR3_ENTRIES >= 1 && TR3_ENTRIES <= 8, "one group of 8 lanes per popped entry");
 constexpr float TR3_BAND = 4.0e-5f;  // float comparisons closer than this are repeated in FP64
 
 struct Force3Args {
@@ -497,14 +500,12 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
 {
     __shared__ uint32_t st_node[4][TR3_STACK];
     __shared__ uint64_t st_mask[4][TR3_STACK];
-    __shared__ uint32_t st_owner[4][64];  // per batch slot: popped entry << 4 | sibling number
     // the batch being visited: per entry {record}, {lane mask, opening threshold, child word}
     __shared__ __attribute__((aligned(16))) uint4 st_batch[4][TR3_BATCH][2];
     __shared__ float st_prune[4][TR3_BATCH];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     uint32_t *snode = st_node[w];
     uint64_t *smask = st_mask[w];
-    uint32_t *owner = st_owner[w];
     uint4(*batch)[2] = st_batch[w];
     float *bprune = st_prune[w];
 
@@ -557,47 +558,26 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
             n_batch += 1;
             max_top = top > max_top ? top : max_top;
         }
-        // Pop: lane e looks at the e-th entry from the top; the entries taken are the longest run
-        // from the top whose child counts add up to at most TR3_BATCH.
-        const int avail = top < 64 ? top : 64;
-        uint32_t ew = 0;
-        if (lane < avail)
-            ew = snode[top - 1 - lane];
-        const uint32_t cnt = ew & 15u;  // 0 beyond the stack
-        uint32_t excl = 0;
-        uint64_t plane[4];
-#pragma unroll
-        for (int bit = 0; bit < 4; ++bit) {
-            plane[bit] = __builtin_amdgcn_ballot_w64(((cnt >> bit) & 1u) != 0u);
-            excl += mbcnt64(plane[bit]) << bit;
-        }
-        uint64_t takem = __builtin_amdgcn_ballot_w64(lane < avail && excl + cnt <= (uint32_t)TR3_BATCH);
+        // Pop: the group of 8 lanes e takes the e-th entry from the top, lane i of it sibling i.
+        int npop = top < TR3_ENTRIES ? top : TR3_ENTRIES;
         if (top > TR3_HIGH)
-            takem = 1ull;
-        int c = 0;
-#pragma unroll
-        for (int bit = 0; bit < 4; ++bit)
-            c += (int)__popcll(plane[bit] & takem) << bit;
-        if (__builtin_amdgcn_inverse_ballot_w64(takem)) {
-#pragma unroll
-            for (uint32_t i = 0; i < 8u; ++i)
-                if (i < cnt)
-                    owner[excl + i] = ((uint32_t)lane << 4) | i;
-        }
-        __builtin_amdgcn_wave_barrier();
+            npop = 1;
+        const int grp = lane >> 3, sib = lane & 7;
         uint32_t u = 0;
         uint64_t um = 0ull;
-        if (lane < c) {
-            const uint32_t o = owner[lane];
-            const int at = top - 1 - (int)(o >> 4);
-            u = (snode[at] >> 4) + (o & 15u);
-            um = smask[at];
+        bool have = false;
+        if (grp < npop) {
+            const uint32_t ew = snode[top - 1 - grp];
+            have = (uint32_t)sib < (ew & 15u);
+            u = (ew >> 4) + (uint32_t)sib;
+            um = smask[top - 1 - grp];
         }
-        const int base = top - (int)__popcll(takem);
+        const uint64_t cmask = __builtin_amdgcn_ballot_w64(have);  // lanes holding a node
+        const int base = top - npop;
         __builtin_amdgcn_wave_barrier();
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         uint4 aux = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < c) {
+        if (have) {
             rec = a.node_rec[u];
             aux = a.node_aux[u];
         }
@@ -607,7 +587,6 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
         // mass to the bounding box of the wave's targets: opened by every lane -> its children go
         // onto the stack right here; accepted by every lane -> force only; far from every lane ->
         // no cutoff and prune tests; the rest and the bodies take the full tests.
-        const uint64_t cmask = c >= 64 ? ~0ull : ((1ull << c) - 1ull);
         const float ex = fmaxf(fmaxf(g0[0] - rec.x, rec.x - g1[0]), 0.f), ey = fmaxf(fmaxf(g0[1] - rec.y, rec.y - g1[1]), 0.f),
                     ez = fmaxf(fmaxf(g0[2] - rec.z, rec.z - g1[2]), 0.f);
         const float fxm = fmaxf(rec.x - g0[0], g1[0] - rec.x), fym = fmaxf(rec.y - g0[1], g1[1] - rec.y),
