@@ -219,8 +219,9 @@ int nb_diagnostics(nb_sim *sim, double *out, int count);
  * theta (src/cpu/barnesHut.cpp:70-71).  The root box is padded and rounded on every axis as
  * BarnesHut::computeBoundingBox does (barnesHut.cpp:23-35); its z range is then widened to its
  * x-width when smaller, so that the cells of a thin disc are not slabs.  For bodies that all lie in the plane z = 0 the results
- * are those of the 2-D entry points.  One GPU per simulation; nb_params.bucket_depth must be 0.
- * Each nb3_ function mirrors the nb_ function of the same name. */
+ * are those of the 2-D entry points.  nb_params.bucket_depth must be 0.
+ * Each nb3_ function mirrors the nb_ function of the same name (the exchange buffer holds records
+ * of 3 doubles). */
 
 typedef struct nb_vec3 {
     double x;
@@ -254,6 +255,11 @@ int nb3_step(nb_sim3 *sim, int nsteps);
 int nb3_compute_accel(nb_sim3 *sim);
 int nb3_read_bodies(nb_sim3 *sim, nb_body3 *out);
 int nb3_sync(nb_sim3 *sim);
+int nb3_set_stream(nb_sim3 *sim, void *hip_stream);
+int nb3_set_partition(nb_sim3 *sim, int rank, int world);
+int nb3_exchange_buffer(nb_sim3 *sim, void **device_ptr, size_t *chunk_records, size_t *record_bytes);
+int nb3_step_local(nb_sim3 *sim);
+int nb3_step_finish(nb_sim3 *sim);
 /* `which` is an nb_debug_array.  Differences from nb_debug_read: NB_DBG_BBOX is 6 doubles
  * (topLeft.x, topLeft.y, botRight.x, botRight.y, upper z, lower z); keys hold 3 bits per level from
  * bit 61 down (at most 20 levels); NB_DBG_NODE_COM is 6 doubles per node (com.x, com.y, com.z, mass,

@@ -60,6 +60,7 @@ ABI_SYMBOLS = [
     "nb_stage_ms", "nb_diagnostics", "nb_refresh_order", "nb_last_error", "nb_version",
     "nb3_init_scenario", "nb3_create", "nb3_destroy", "nb3_setup", "nb3_set_bodies", "nb3_step",
     "nb3_compute_accel", "nb3_read_bodies", "nb3_sync", "nb3_debug_read", "nb3_set_stage_timing", "nb3_stage_ms",
+    "nb3_set_stream", "nb3_set_partition", "nb3_exchange_buffer", "nb3_step_local", "nb3_step_finish",
 ]
 
 
@@ -127,6 +128,11 @@ def load_library(path=None):
     lib.nb3_read_bodies.argtypes = [vp, vp]
     lib.nb3_sync.argtypes = [vp]
     lib.nb3_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.nb3_set_stream.argtypes = [vp, vp]
+    lib.nb3_set_partition.argtypes = [vp, i, i]
+    lib.nb3_exchange_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.nb3_step_local.argtypes = [vp]
+    lib.nb3_step_finish.argtypes = [vp]
     lib.nb3_set_stage_timing.argtypes = [vp, i]
     lib.nb3_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]
     lib.nb_last_error.restype = C.c_char_p
@@ -177,7 +183,10 @@ class NBodySim:
         self.params = params or default_params()
         _check(self._lib.nb_create(C.byref(self.params), self.n, alg, C.byref(self._h)))
         if stream is not None:
-            _check(self._lib.nb_set_stream(self._h, C.c_void_p(stream)))
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        _check(self._lib.nb_set_stream(self._h, C.c_void_p(stream)))
 
     # -- reference surface --
     def setup(self, sim, seed=12345):
@@ -277,15 +286,35 @@ def init_scenario3(sim, n, seed=12345, thickness=0.0):
 
 
 class NBodySim3:
-    """NBodySim for three-dimensional bodies (the nb3_ entry points; one GPU)."""
+    """NBodySim for three-dimensional bodies (the nb3_ entry points)."""
 
-    def __init__(self, n, alg=BARNES_HUT, params=None):
+    def __init__(self, n, alg=BARNES_HUT, params=None, stream=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.n = int(n)
         self.alg = alg
         self.params = params or default_params()
         _check(self._lib.nb3_create(C.byref(self.params), self.n, alg, C.byref(self._h)))
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        _check(self._lib.nb3_set_stream(self._h, C.c_void_p(stream)))
+
+    def set_partition(self, rank, world):
+        _check(self._lib.nb3_set_partition(self._h, rank, world))
+
+    def exchange_buffer(self):
+        """(device pointer, records per rank, bytes per record) of the position exchange buffer."""
+        p, c, r = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _check(self._lib.nb3_exchange_buffer(self._h, C.byref(p), C.byref(c), C.byref(r)))
+        return p.value, c.value, r.value
+
+    def step_local(self):
+        _check(self._lib.nb3_step_local(self._h))
+
+    def step_finish(self):
+        _check(self._lib.nb3_step_finish(self._h))
 
     def setup(self, sim, seed=12345, thickness=0.0):
         _check(self._lib.nb3_setup(self._h, sim, seed, thickness))

@@ -18,6 +18,7 @@ struct nb_sim3 {
     int n = 0;
     int alg = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = false;
     bool have_bodies = false;
     bool first_kick = true;   // leapfrog: the next step is the first since the bodies were set
     long steps_in_order = 0;  // direct sum: steps since the order was last derived from the positions
@@ -29,6 +30,13 @@ struct nb_sim3 {
     double *mass = nullptr, *radius = nullptr;
     uint8_t *dyn = nullptr;
     std::vector<uint32_t> order;  // caller index of the body in each slot
+
+    // partition: this process integrates slots [t0, t1)
+    int rank = 0, world = 1;
+    size_t chunk = 0;
+    int t0 = 0, t1 = 0;
+    bool mid_step = false;
+    size_t part_cap = 0;  // doubles in ds.part
 
     Direct3State ds;
     Bh3Buffers bh;
@@ -134,18 +142,15 @@ void mark(nb_sim3 *s, int k)
         (void)hipEventRecord(s->ev[s->ev_used][k], s->stream);
 }
 
-int step_once(nb_sim3 *s, int do_integrate)
+int step_local(nb_sim3 *s, int do_integrate)
 {
     if (s->alg == NB_ALG_DIRECT) {
         s->ds.pos_cur = s->pos;
         s->ds.pos_next = s->pos2;
         mark(s, 0);
-        NB_TRY(direct3_step(s->stream, s->ds, s->n, s->fc, integrate_args(s, do_integrate), s->p.collision_th));
+        NB_TRY(direct3_step(s->stream, s->ds, s->n, s->t0, s->t1 - s->t0, s->fc, integrate_args(s, do_integrate),
+                            s->p.collision_th));
         mark(s, 1);
-        if (do_integrate) {
-            s->ds.cur ^= 1;
-            std::swap(s->pos, s->pos2);
-        }
         return NB_OK;
     }
     Bh3StepArgs a;
@@ -156,6 +161,8 @@ int step_once(nb_sim3 *s, int do_integrate)
     a.vel = s->vel;
     a.acc = s->acc;
     a.n = s->n;
+    a.t0 = s->t0;
+    a.t1 = s->t1;
     a.units = s->units;
     a.fc = s->fc;
     a.ia = integrate_args(s, do_integrate);
@@ -176,6 +183,22 @@ int step_once(nb_sim3 *s, int do_integrate)
     mark(s, 5);
     NB_TRY(bh3_force(s->stream, s->bh, a));
     mark(s, 6);
+    return NB_OK;
+}
+
+// After the positions other ranks advanced have been gathered into the new position buffer.
+int step_finish(nb_sim3 *s)
+{
+    s->first_kick = false;
+    if (s->alg == NB_ALG_DIRECT) {
+        if (s->world > 1) {
+            const double il = 1.0 / s->units.len_unit, im = 1.0 / s->units.mass_unit;
+            NB_TRY(pack_posm3_range(s->stream, s->pos2, s->mass, 0, s->t0, il, im, s->ds.posm[s->ds.cur ^ 1]));
+            NB_TRY(pack_posm3_range(s->stream, s->pos2, s->mass, s->t1, s->n, il, im, s->ds.posm[s->ds.cur ^ 1]));
+        }
+        s->ds.cur ^= 1;
+        std::swap(s->pos, s->pos2);
+    }
     return NB_OK;
 }
 
@@ -226,7 +249,7 @@ void release(nb_sim3 *s)
         for (auto &e : set)
             if (e)
                 (void)hipEventDestroy(e);
-    if (s->stream)
+    if (s->own_stream && s->stream)
         (void)hipStreamDestroy(s->stream);
 }
 
@@ -337,7 +360,10 @@ int nb3_create(const nb_params *params, int n, int alg, nb_sim3 **out)
     };
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
         chk(fail(NB_ERR_HIP, "hipStreamCreate failed"));
-    const size_t cap = (size_t)n + 64;
+    s->own_stream = rc == NB_OK;
+    s->t1 = n;
+    s->chunk = (size_t)n;
+    const size_t cap = (size_t)n + 64;  // room for world * chunk records (world <= 64)
     chk(dev_alloc(s->pos, 3 * cap));
     chk(dev_alloc(s->vel, 3 * cap));
     chk(dev_alloc(s->acc, 3 * cap));
@@ -351,7 +377,8 @@ int nb3_create(const nb_params *params, int n, int alg, nb_sim3 **out)
         chk(dev_alloc(s->ds.wcut, direct3_record_capacity(n)));
         chk(dev_alloc(s->ds.rad, cap));
         s->ds.jsplit = direct3_choose_jsplit(n, n);
-        chk(dev_alloc(s->ds.part, 3 * (size_t)s->ds.jsplit * n));
+        s->part_cap = 3 * (size_t)s->ds.jsplit * n;
+        chk(dev_alloc(s->ds.part, s->part_cap));
         uint8_t *meta = nullptr;
         chk(dev_alloc(meta, direct3_meta_bytes(n)));
         s->ds.meta = meta;
@@ -398,6 +425,7 @@ int nb3_set_bodies(nb_sim3 *s, const nb_body3 *b, int n)
     NB_TRY(load_bodies(s, b, n));
     s->have_bodies = true;
     s->first_kick = true;
+    s->mid_step = false;
     return NB_OK;
 }
 
@@ -420,13 +448,15 @@ int nb3_step(nb_sim3 *s, int nsteps)
         return fail(NB_ERR_ARG, "nb3_step: nsteps < 0");
     if (!s->have_bodies)
         return fail(NB_ERR_STATE, "nb3_step: no bodies were set");
+    if (s->world != 1)
+        return fail(NB_ERR_STATE, "nb3_step: a partitioned simulation steps with nb3_step_local / nb3_step_finish");
     // direct sum: bodies wander, so the spatial order its run-against-block tests rely on is
     // renewed now and then (same rule as nb_step)
     long interval = 50000000L / s->n;
     interval = interval < 64 ? 64 : (interval > 4096 ? 4096 : interval);
     for (int k = 0; k < nsteps; ++k) {
-        NB_TRY(step_once(s, 1));
-        s->first_kick = false;
+        NB_TRY(step_local(s, 1));
+        NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
         if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= interval) {
             std::vector<nb_body3> b(s->n);
@@ -443,7 +473,9 @@ int nb3_compute_accel(nb_sim3 *s)
         return fail(NB_ERR_ARG, "nb3_compute_accel: sim is NULL");
     if (!s->have_bodies)
         return fail(NB_ERR_STATE, "nb3_compute_accel: no bodies were set");
-    NB_TRY(step_once(s, 0));
+    if (s->mid_step)
+        return fail(NB_ERR_STATE, "nb3_compute_accel: a split step is in flight");
+    NB_TRY(step_local(s, 0));
     return collect_timing(s);
 }
 
@@ -463,10 +495,85 @@ int nb3_read_bodies(nb_sim3 *s, nb_body3 *out)
         return fail(NB_ERR_STATE, "nb3_read_bodies: no bodies were set");
     // leapfrog keeps velocities half a step behind the positions; bring them level with the
     // force at the current positions
-    const bool half_step = s->p.integrator == NB_INT_LEAPFROG && !s->first_kick;
+    const bool half_step = s->p.integrator == NB_INT_LEAPFROG && !s->first_kick && !s->mid_step;
     if (half_step)
-        NB_TRY(step_once(s, 0));
+        NB_TRY(step_local(s, 0));
     return read_state(s, out, half_step ? 0.5 * s->p.dt : 0.0);
+}
+
+int nb3_set_stream(nb_sim3 *s, void *hip_stream)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb3_set_stream: sim is NULL");
+    NB_HIP(hipStreamSynchronize(s->stream));
+    if (s->own_stream && s->stream)
+        (void)hipStreamDestroy(s->stream);
+    s->stream = (hipStream_t)hip_stream;
+    s->own_stream = false;
+    return NB_OK;
+}
+
+int nb3_set_partition(nb_sim3 *s, int rank, int world)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb3_set_partition: sim is NULL");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world)
+        return fail(NB_ERR_ARG, "nb3_set_partition: need 0 <= rank < world <= 64");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb3_set_partition: set the bodies first");
+    s->rank = rank;
+    s->world = world;
+    s->chunk = ((size_t)s->n + world - 1) / world;
+    s->t0 = (int)std::min((size_t)s->n, rank * s->chunk);
+    s->t1 = (int)std::min((size_t)s->n, (rank + 1) * s->chunk);
+    if (s->alg == NB_ALG_DIRECT) {
+        // fewer targets per rank: split the sources further so the chip stays full
+        const int js = direct3_choose_jsplit(s->n, s->t1 - s->t0);
+        const size_t need = 3 * (size_t)js * (size_t)(s->t1 - s->t0);
+        if (need > s->part_cap) {
+            (void)hipFree(s->ds.part);
+            s->ds.part = nullptr;
+            NB_TRY(dev_alloc(s->ds.part, need));
+            s->part_cap = need;
+        }
+        s->ds.jsplit = js;
+    }
+    return NB_OK;
+}
+
+int nb3_exchange_buffer(nb_sim3 *s, void **device_ptr, size_t *chunk_records, size_t *record_bytes)
+{
+    if (!s || !device_ptr || !chunk_records || !record_bytes)
+        return fail(NB_ERR_ARG, "nb3_exchange_buffer: NULL argument");
+    // direct sum writes the new positions to the other buffer; mid-step that is the one to gather
+    *device_ptr = (s->alg == NB_ALG_DIRECT && s->mid_step) ? s->pos2 : s->pos;
+    *chunk_records = s->chunk;
+    *record_bytes = 3 * sizeof(double);
+    return NB_OK;
+}
+
+int nb3_step_local(nb_sim3 *s)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb3_step_local: sim is NULL");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb3_step_local: no bodies were set");
+    if (s->mid_step)
+        return fail(NB_ERR_STATE, "nb3_step_local: the previous step was not finished");
+    NB_TRY(step_local(s, 1));
+    s->mid_step = true;
+    return NB_OK;
+}
+
+int nb3_step_finish(nb_sim3 *s)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb3_step_finish: sim is NULL");
+    if (!s->mid_step)
+        return fail(NB_ERR_STATE, "nb3_step_finish: nb3_step_local was not called");
+    NB_TRY(step_finish(s));
+    s->mid_step = false;
+    return collect_timing(s);
 }
 
 int nb3_set_stage_timing(nb_sim3 *s, int on)

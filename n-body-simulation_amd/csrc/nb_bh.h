@@ -88,6 +88,11 @@ size_t build_split_bytes(int bits);
 int launched_levels(const uint32_t *levels_host);
 int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node_meta, void *split, uint32_t *level_start,
                uint32_t *bsum, unsigned long long *counters, int launched);
+// Sorted positions k whose body sorted_idx[k] lies in [t0, t1), ascending, into tlist (n words);
+// their number into *tcount; tblock: target_list_blocks(n) words of scratch.
+size_t target_list_blocks(int n);
+int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int t1, uint32_t *tblock, uint32_t *tlist,
+                   uint32_t *tcount);
 // counters[2] = nodes, [3] = levels; *levels_host = levels (pinned host word).
 int bh_finish(hipStream_t s, const uint32_t *level_start, unsigned long long *counters, uint32_t *levels_host);
 

@@ -1505,6 +1505,19 @@ __global__ void k_bh_finish_counters(const uint32_t *level_start, unsigned long 
     }
 }
 
+size_t target_list_blocks(int n) { return (size_t)(n + TL_TILE - 1) / TL_TILE + 1; }
+
+int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int t1, uint32_t *tblock, uint32_t *tlist,
+                   uint32_t *tcount)
+{
+    const int nblk = (n + TL_TILE - 1) / TL_TILE;
+    hipLaunchKernelGGL(k_tl_count, dim3(nblk), dim3(256), 0, s, sorted_idx, n, (uint32_t)t0, (uint32_t)t1, tblock);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, tblock, nblk);
+    hipLaunchKernelGGL(k_tl_emit, dim3(nblk), dim3(256), 0, s, sorted_idx, n, (uint32_t)t0, (uint32_t)t1, tblock, tlist, tcount);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
 int bh_finish(hipStream_t s, const uint32_t *level_start, unsigned long long *counters, uint32_t *levels_host)
 {
     hipLaunchKernelGGL(k_bh_finish_counters, dim3(1), dim3(64), 0, s, level_start, counters, levels_host);
@@ -1528,12 +1541,7 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     int ntarget = a.n;
     if (a.t0 != 0 || a.t1 != a.n) {
         // this rank integrates only bodies [t0, t1): walk them in Morton order
-        const int nblk = (a.n + TL_TILE - 1) / TL_TILE;
-        hipLaunchKernelGGL(k_tl_count, dim3(nblk), dim3(256), 0, s, b.idx[b.sorted], a.n, (uint32_t)a.t0, (uint32_t)a.t1,
-                           b.tblock);
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, b.tblock, nblk);
-        hipLaunchKernelGGL(k_tl_emit, dim3(nblk), dim3(256), 0, s, b.idx[b.sorted], a.n, (uint32_t)a.t0, (uint32_t)a.t1,
-                           b.tblock, b.tlist, b.tcount);
+        NB_TRY(bh_target_list(s, b.idx[b.sorted], a.n, a.t0, a.t1, b.tblock, b.tlist, b.tcount));
         f.tlist = b.tlist;
         f.tcount = b.tcount;
         ntarget = a.t1 - a.t0;
@@ -1607,7 +1615,7 @@ int bh_alloc(BhBuffers &b, int n)
     NB_TRY(dev_alloc(b.node_child, b.node_cap));
     NB_TRY(dev_alloc(b.tlist, (size_t)n));
     NB_TRY(dev_alloc(b.tcount, 4));
-    NB_TRY(dev_alloc(b.tblock, (size_t)(n + TL_TILE - 1) / TL_TILE + 1));
+    NB_TRY(dev_alloc(b.tblock, target_list_blocks(n)));
     NB_TRY(dev_alloc(b.counters, 8));
     {
         void *h = nullptr;

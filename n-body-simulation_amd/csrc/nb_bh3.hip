@@ -468,6 +468,8 @@ struct Force3Args {
     const uint4 *node_aux;
     const double *node_com;
     const uint32_t *idx;
+    const uint32_t *tlist;   // may be null: targets are all sorted bodies
+    const uint32_t *tcount;  // device count of tlist entries (when tlist != null)
     const uint8_t *dyn;
     const double *radius;
     double *pos, *vel, *acc;
@@ -509,11 +511,13 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
     uint4(*batch)[2] = st_batch[w];
     float *bprune = st_prune[w];
 
-    const int k = (blockIdx.x * 4 + w) * 64 + lane;
-    if ((blockIdx.x * 4 + w) * 64 >= a.n)
+    const int ntarget = a.tlist ? (int)*a.tcount : a.n;
+    const int slot = (blockIdx.x * 4 + w) * 64 + lane;
+    if ((blockIdx.x * 4 + w) * 64 >= ntarget)
         return;  // whole wave idle (no block barriers below)
-    const bool valid = k < a.n;
-    const int ks = valid ? k : a.n - 1;
+    const bool valid = slot < ntarget;
+    const int last = valid ? slot : ntarget - 1;
+    const int ks = a.tlist ? (int)a.tlist[last] : last;
     const uint32_t body = a.idx[ks];
     const float4 me = a.posm_s[ks];
     const float xi = me.x, yi = me.y, zi = me.z, ri = a.rad_s[ks];
@@ -811,6 +815,18 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     f.node_aux = b.node_aux;
     f.node_com = b.node_com;
     f.idx = b.idx[0];
+    f.tlist = nullptr;
+    f.tcount = nullptr;
+    int ntarget = a.n;
+    if (a.t0 != 0 || a.t1 != a.n) {
+        // this rank integrates only bodies [t0, t1): walk them in Morton order
+        NB_TRY(bh_target_list(s, b.idx[0], a.n, a.t0, a.t1, b.tblock, b.tlist, b.tcount));
+        f.tlist = b.tlist;
+        f.tcount = b.tcount;
+        ntarget = a.t1 - a.t0;
+    }
+    if (ntarget <= 0)
+        return bh_finish(s, b.level_start, b.counters, b.levels_host);
     f.dyn = a.dyn;
     f.radius = a.radius;
     f.pos = a.pos;
@@ -822,7 +838,7 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     f.ia = a.ia;
     f.theta = a.theta;
     f.collision_th = a.collision_th;
-    const int waves = (a.n + 63) / 64;
+    const int waves = (ntarget + 63) / 64;
     const dim3 grid((waves + 3) / 4);
     const int mode = a.fc.exact_denom ? F3_EXACT : (a.fc.eps2_negligible ? F3_NOEPS : F3_EPS);
     if (a.collect_stats) {
@@ -884,6 +900,9 @@ int bh3_alloc(Bh3Buffers &b, int n)
     NB_TRY(dev_alloc3(b.node_com, 6 * b.node_cap));
     NB_TRY(dev_alloc3(b.node_rec, b.node_cap));
     NB_TRY(dev_alloc3(b.node_aux, b.node_cap));
+    NB_TRY(dev_alloc3(b.tlist, (size_t)n));
+    NB_TRY(dev_alloc3(b.tcount, 4));
+    NB_TRY(dev_alloc3(b.tblock, target_list_blocks(n)));
     NB_TRY(dev_alloc3(b.counters, 8));
     void *h = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
@@ -914,6 +933,9 @@ void bh3_free(Bh3Buffers &b)
     (void)hipFree(b.node_com);
     (void)hipFree(b.node_rec);
     (void)hipFree(b.node_aux);
+    (void)hipFree(b.tlist);
+    (void)hipFree(b.tcount);
+    (void)hipFree(b.tblock);
     (void)hipFree(b.counters);
     if (b.levels_host)
         (void)hipHostFree(b.levels_host);

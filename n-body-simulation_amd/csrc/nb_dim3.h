@@ -26,7 +26,7 @@ struct Direct3State {
     double *pos_next = nullptr;
     const double *radius = nullptr;
     double *vel = nullptr, *acc = nullptr;
-    double *part = nullptr;  // jsplit x n x 3 partial sums
+    double *part = nullptr;  // jsplit x targets x 3 partial sums
     int jsplit = 1;
     void *meta = nullptr;  // direct3_meta_bytes(n)
 };
@@ -37,8 +37,12 @@ int direct3_choose_jsplit(int n, int nt);
 // Fills posm[0..cap), wcut[0..cap) and rad[0..n) from the FP64 state (cap = direct3_record_capacity).
 int pack_posm3(hipStream_t s, const double *pos, const double *mass, const double *radius, int n, double inv_len_unit,
                double inv_mass_unit, double collision_th, float4 *posm, float *wcut, float *rad);
-// One step: reads posm[cur] and pos_cur, writes vel, acc, pos_next and posm[cur ^ 1].
-int direct3_step(hipStream_t s, const Direct3State &st, int n, const ForceConsts &fc, const IntegrateArgs &ia,
+// Records of bodies [i0, i1) only (the ones other ranks advanced, from the gathered positions).
+int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int i0, int i1, double inv_len_unit,
+                     double inv_mass_unit, float4 *posm);
+// One step for targets [t0, t0 + nt): reads posm[cur] and pos_cur, writes the targets' vel, acc,
+// pos_next and posm[cur ^ 1].
+int direct3_step(hipStream_t s, const Direct3State &st, int n, int t0, int nt, const ForceConsts &fc, const IntegrateArgs &ia,
                  double collision_th);
 
 // ---- Barnes-Hut (nb_bh3.hip) ----
@@ -66,6 +70,9 @@ struct Bh3Buffers {
     uint4 *node_aux = nullptr;    // x = float bits of (width/theta)^2, or of -(radius + collision_th) for a
                                   // leaf; y = first child << 4 | child count; z = float bits of the prune
                                   // threshold (collision_th - cell diagonal)^2 or -1
+    uint32_t *tlist = nullptr;    // sorted positions of this rank's targets (partitioned runs)
+    uint32_t *tcount = nullptr;
+    uint32_t *tblock = nullptr;
     unsigned long long *counters = nullptr;
     uint32_t *levels_host = nullptr;
     int launched = 0;
@@ -79,6 +86,7 @@ struct Bh3StepArgs {
     double *vel;
     double *acc;
     int n;
+    int t0, t1;  // slots of the bodies this rank integrates
     Units units;
     ForceConsts fc;
     IntegrateArgs ia;

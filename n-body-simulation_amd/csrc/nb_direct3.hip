@@ -415,9 +415,33 @@ int direct3_choose_jsplit(int n, int nt)
     return want < 1 ? 1 : want;
 }
 
-int direct3_step(hipStream_t s, const Direct3State &st, int n, const ForceConsts &fc, const IntegrateArgs &ia,
+__global__ __launch_bounds__(256) void k_pack_posm3_range(const double *pos, const double *mass, int i0, int i1, double inv_len,
+                                                          double inv_mass, float4 *posm)
+{
+    const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < i1)
+        posm[i] = make_float4((float)(pos[3 * (size_t)i] * inv_len), (float)(pos[3 * (size_t)i + 1] * inv_len),
+                              (float)(pos[3 * (size_t)i + 2] * inv_len), (float)(mass[i] * inv_mass));
+}
+
+int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int i0, int i1, double inv_len_unit,
+                     double inv_mass_unit, float4 *posm)
+{
+    if (i1 <= i0)
+        return NB_OK;
+    hipLaunchKernelGGL(k_pack_posm3_range, dim3((i1 - i0 + 255) / 256), dim3(256), 0, s, pos, mass, i0, i1, inv_len_unit,
+                       inv_mass_unit, posm);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+int direct3_step(hipStream_t s, const Direct3State &st, int n, int t0, int nt, const ForceConsts &fc, const IntegrateArgs &ia,
                  double collision_th)
 {
+    if (nt <= 0)
+        return NB_OK;
+    if (t0 < 0 || t0 + nt > n)
+        return fail(NB_ERR_ARG, "direct3_step: bad target range");
     Direct3Launch a;
     a.posm_cur = st.posm[st.cur];
     a.posm_next = st.posm[st.cur ^ 1];
@@ -433,8 +457,8 @@ int direct3_step(hipStream_t s, const Direct3State &st, int n, const ForceConsts
     a.acc = st.acc;
     a.part = st.part;
     a.n = n;
-    a.t0 = 0;
-    a.nt = n;
+    a.t0 = t0;
+    a.nt = nt;
     const int ntiles = (n + DS3_TILE - 1) / DS3_TILE;
     a.tiles_per_split = (ntiles + st.jsplit - 1) / st.jsplit;
     a.jsplit = (ntiles + a.tiles_per_split - 1) / a.tiles_per_split;  // no empty splits
@@ -444,14 +468,14 @@ int direct3_step(hipStream_t s, const Direct3State &st, int n, const ForceConsts
         return fail(NB_ERR_ARG, "direct3_step: split sources need a partial buffer");
     const int nsub = (n + DS3_SUB - 1) / DS3_SUB;
     hipLaunchKernelGGL(k_sub_meta3, dim3((nsub + 3) / 4), dim3(256), 0, s, a.posm_cur, a.wcut, n, (SubMeta3 *)st.meta);
-    dim3 grid((n + DS3_BLOCK * DS3_TPT - 1) / (DS3_BLOCK * DS3_TPT), a.jsplit);
+    dim3 grid((nt + DS3_BLOCK * DS3_TPT - 1) / (DS3_BLOCK * DS3_TPT), a.jsplit);
     if (fc.exact_denom)
         hipLaunchKernelGGL((k_direct3<DS3_TPT, true>), grid, dim3(DS3_BLOCK), 0, s, a);
     else
         hipLaunchKernelGGL((k_direct3<DS3_TPT, false>), grid, dim3(DS3_BLOCK), 0, s, a);
     NB_HIP(hipGetLastError());
     if (a.jsplit > 1) {
-        hipLaunchKernelGGL(k_direct3_finish, dim3((n + 255) / 256), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_direct3_finish, dim3((nt + 255) / 256), dim3(256), 0, s, a);
         NB_HIP(hipGetLastError());
     }
     return NB_OK;

@@ -6,10 +6,10 @@ The reference is single-GPU; this layer has no counterpart there.  The engine it
 only has to offer
 
     n, set_partition(rank, world), step_local(), step_finish(),
-    exchange_tensor() -> torch tensor [world * chunk, 2] float64 holding every body's position,
+    exchange_tensor() -> torch tensor [world * chunk, 2 or 3] float64 holding every body's position,
                          this rank's slice up to date after step_local()
 
-which NBodySim (below, through its exchange buffer) and the CPU test engine both do.
+which NBodySim and NBodySim3 (below, through their exchange buffers) and the CPU test engine all do.
 """
 import numpy as np
 import torch
@@ -34,20 +34,20 @@ class _DevicePointer:
         }
 
 
-def device_tensor(ptr, records, device):
-    """A float64 [records, 2] tensor aliasing `records` 16-byte position records at ptr."""
-    t = torch.as_tensor(_DevicePointer(ptr, records * 16), device=device)
-    return t.view(torch.float64).view(records, 2)
+def device_tensor(ptr, records, device, width=2):
+    """A float64 [records, width] tensor aliasing `records` position records of width doubles at ptr."""
+    t = torch.as_tensor(_DevicePointer(ptr, records * 8 * width), device=device)
+    return t.view(torch.float64).view(records, width)
 
 
 class GpuEngine:
-    """NBodySim behind the engine protocol; its kernels run on torch's current stream."""
+    """NBodySim or NBodySim3 behind the engine protocol; its kernels run on torch's current stream."""
 
     def __init__(self, sim, device):
         self.sim = sim
         self.n = sim.n
         self.device = device
-        sim._lib.nb_set_stream(sim._h, torch.cuda.current_stream(device).cuda_stream)
+        sim.set_stream(torch.cuda.current_stream(device).cuda_stream)
         self._cache = {}
 
     def set_partition(self, rank, world):
@@ -62,10 +62,10 @@ class GpuEngine:
 
     def exchange_tensor(self):
         ptr, chunk, rec = self.sim.exchange_buffer()
-        assert rec == 16
+        assert rec in (16, 24)
         t = self._cache.get(ptr)
         if t is None:
-            t = device_tensor(ptr, chunk * self.world, self.device)
+            t = device_tensor(ptr, chunk * self.world, self.device, rec // 8)
             self._cache[ptr] = t
         return t
 

@@ -215,6 +215,50 @@ def test_large_bh3_against_direct3(nb, oracle):
     assert np.median(rel_err(tight, a_ds)) < np.median(err) / 3
 
 
+@pytest.mark.parametrize("alg", [0, 1])
+def test_two_rank_partition_equals_single_rank(nb, oracle, alg):
+    """Two handles own half the targets each; positions travel through the exchange buffers as an
+    all-gather would move them (records of three doubles)."""
+    import ctypes as C
+
+    n = 3001
+    b = oracle.scenario3(0, n, 8, thickness=5.0e10)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    with nb.NBodySim3(n, alg) as one, nb.NBodySim3(n, alg) as r0, nb.NBodySim3(n, alg) as r1:
+        for s in (one, r0, r1):
+            s.set_bodies(b)
+        r0.set_partition(0, 2)
+        r1.set_partition(1, 2)
+        with pytest.raises(nb.NBodyError, match="partitioned"):
+            r0.update()
+        for _ in range(5):
+            one.update()
+            for s in (r0, r1):
+                s.step_local()
+            for s in (r0, r1):
+                s.sync()
+            p0, chunk, rb = r0.exchange_buffer()
+            p1, _, _ = r1.exchange_buffer()
+            assert chunk == (n + 1) // 2 and rb == 24
+            assert hip.hipMemcpy(p1, p0, chunk * rb, 3) == 0
+            assert hip.hipMemcpy(p0 + chunk * rb, p1 + chunk * rb, (n - chunk) * rb, 3) == 0
+            for s in (r0, r1):
+                s.step_finish()
+        ref = one.read_bodies()
+        a = r0.read_bodies()
+        c = r1.read_bodies()
+        order = r0.order()
+    assert np.array_equal(a["pos"], c["pos"])
+    # Barnes-Hut: the same tree and the same per-body decisions on every rank, only the 64-body
+    # groups differ (FP32 summation order); direct sum likewise
+    assert np.linalg.norm(a["pos"] - ref["pos"], axis=1).max() <= 1e-9 * 5e11
+    own0, own1 = order[:chunk], order[chunk:]  # each rank keeps velocities of its own slots only
+    vmax = np.linalg.norm(ref["vel"], axis=1).max()
+    assert np.linalg.norm(a["vel"][own0] - ref["vel"][own0], axis=1).max() <= 1e-6 * vmax
+    assert np.linalg.norm(c["vel"][own1] - ref["vel"][own1], axis=1).max() <= 1e-6 * vmax
+
+
 def test_argument_checks(nb):
     with pytest.raises(nb.NBodyError):
         nb.NBodySim3(0, nb.DIRECT)

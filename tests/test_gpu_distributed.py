@@ -58,3 +58,33 @@ def test_distributed_stepper_world1_matches_plain_update(nb, oracle, nccl_group,
         assert np.array_equal(t.cpu().numpy(), a["pos"][part.order()])
     assert np.array_equal(a["pos"], ref["pos"])
     assert np.array_equal(a["vel"], ref["vel"])
+
+
+@pytest.mark.parametrize("alg", [0, 1])
+def test_distributed_stepper_world1_matches_plain_update_3d(nb, oracle, nccl_group, alg):
+    """The same through the nb3_ entry points: the exchange tensor has three columns."""
+    import torch
+    from nbody_amd.distributed import DistributedSim, GpuEngine, device_tensor
+
+    n = 4099
+    b = oracle.scenario3(0, n, 3, thickness=5.0e10)
+    dev = torch.device("cuda", 0)
+    with nb.NBodySim3(n, alg) as plain, nb.NBodySim3(n, alg) as part:
+        plain.set_bodies(b)
+        part.set_bodies(b)
+        eng = GpuEngine(part, dev)
+        stepper = DistributedSim(eng)
+        for _ in range(4):
+            plain.update()
+            eng.step_local()
+            stepper.all_gather_positions()
+            eng.step_finish()
+        torch.cuda.synchronize()
+        ptr, chunk, rec = part.exchange_buffer()
+        assert rec == 24
+        t = device_tensor(ptr, n, dev, 3)
+        a = part.read_bodies()
+        ref = plain.read_bodies()
+        assert np.array_equal(t.cpu().numpy(), a["pos"][part.order()])
+    assert np.array_equal(a["pos"], ref["pos"])
+    assert np.array_equal(a["vel"], ref["vel"])
