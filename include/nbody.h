@@ -265,6 +265,9 @@ int nb3_step_finish(nb_sim3 *sim);
  * bit 61 down (at most 20 levels); NB_DBG_NODE_COM is 6 doubles per node (com.x, com.y, com.z, mass,
  * cell x-width or minus the body's radius, 0); NB_DBG_KEYS is not available. */
 int nb3_debug_read(nb_sim3 *sim, int which, void *out, size_t bytes, size_t *written);
+/* out[0] total mass, [1..3] centre of mass, [4..6] momentum, [7..9] angular momentum about the origin,
+ * [10] kinetic energy, [11] potential energy (NaN when n > 131072), as nb_diagnostics defines them. */
+int nb3_diagnostics(nb_sim3 *sim, double *out, int count);
 int nb3_set_stage_timing(nb_sim3 *sim, int on);
 int nb3_stage_ms(nb_sim3 *sim, float *out, int count);
 

@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "nb_stage_ms", "nb_diagnostics", "nb_refresh_order", "nb_last_error", "nb_version",
     "nb3_init_scenario", "nb3_create", "nb3_destroy", "nb3_setup", "nb3_set_bodies", "nb3_step",
     "nb3_compute_accel", "nb3_read_bodies", "nb3_sync", "nb3_debug_read", "nb3_set_stage_timing", "nb3_stage_ms",
-    "nb3_set_stream", "nb3_set_partition", "nb3_exchange_buffer", "nb3_step_local", "nb3_step_finish",
+    "nb3_diagnostics", "nb3_set_stream", "nb3_set_partition", "nb3_exchange_buffer", "nb3_step_local", "nb3_step_finish",
 ]
 
 
@@ -128,6 +128,7 @@ def load_library(path=None):
     lib.nb3_read_bodies.argtypes = [vp, vp]
     lib.nb3_sync.argtypes = [vp]
     lib.nb3_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.nb3_diagnostics.argtypes = [vp, C.POINTER(C.c_double), i]
     lib.nb3_set_stream.argtypes = [vp, vp]
     lib.nb3_set_partition.argtypes = [vp, i, i]
     lib.nb3_exchange_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
@@ -350,6 +351,13 @@ class NBodySim3:
 
     def order(self):
         return self.debug(DBG_ORDER, np.uint32, self.n)
+
+    def diagnostics(self):
+        """Conserved quantities of the current state (FP64); potential is NaN above 131072 bodies."""
+        out = (C.c_double * 12)()
+        _check(self._lib.nb3_diagnostics(self._h, out, 12))
+        return {"mass": out[0], "com": tuple(out[1:4]), "momentum": tuple(out[4:7]), "angular_momentum": tuple(out[7:10]),
+                "kinetic": out[10], "potential": out[11]}
 
     def debug(self, which, dtype, count):
         out = np.zeros(count, dtype=dtype)

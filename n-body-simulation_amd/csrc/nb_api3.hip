@@ -501,6 +501,47 @@ int nb3_read_bodies(nb_sim3 *s, nb_body3 *out)
     return read_state(s, out, half_step ? 0.5 * s->p.dt : 0.0);
 }
 
+int nb3_diagnostics(nb_sim3 *s, double *out, int count)
+{
+    if (!s || !out || count < 1)
+        return fail(NB_ERR_ARG, "nb3_diagnostics: bad argument");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb3_diagnostics: no bodies were set");
+    std::vector<nb_body3> b(s->n);
+    NB_TRY(nb3_read_bodies(s, b.data()));
+    double v[12] = {};
+    for (const nb_body3 &x : b) {
+        const nb_vec3 &p = x.position, &w = x.velocity;
+        v[0] += x.mass;
+        v[1] += x.mass * p.x;
+        v[2] += x.mass * p.y;
+        v[3] += x.mass * p.z;
+        v[4] += x.mass * w.x;
+        v[5] += x.mass * w.y;
+        v[6] += x.mass * w.z;
+        v[7] += x.mass * (p.y * w.z - p.z * w.y);
+        v[8] += x.mass * (p.z * w.x - p.x * w.z);
+        v[9] += x.mass * (p.x * w.y - p.y * w.x);
+        v[10] += 0.5 * x.mass * (w.x * w.x + w.y * w.y + w.z * w.z);
+    }
+    if (v[0] != 0)
+        for (int k = 1; k <= 3; ++k)
+            v[k] /= v[0];
+    v[11] = std::nan("");
+    if (count > 11 && s->n <= 131072) {
+        double *d = nullptr;
+        NB_TRY(dev_alloc(d, 1));
+        int rc = potential_energy3(s->stream, s->pos, s->mass, s->radius, s->n, s->p.gravity, s->p.eps, s->p.collision_th, d);
+        if (rc == NB_OK && hipStreamSynchronize(s->stream) == hipSuccess)
+            (void)hipMemcpy(&v[11], d, sizeof(double), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        NB_TRY(rc);
+    }
+    for (int k = 0; k < count && k < 12; ++k)
+        out[k] = v[k];
+    return NB_OK;
+}
+
 int nb3_set_stream(nb_sim3 *s, void *hip_stream)
 {
     if (!s)

@@ -81,4 +81,7 @@ int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const doubl
 int potential_energy(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int n, double gravity,
                      double eps, double collision_th, double *out);
 
+int potential_energy3(hipStream_t s, const double *pos, const double *mass, const double *radius, int n, double gravity,
+                      double eps, double collision_th, double *out);
+
 }  // namespace nb
