@@ -1041,17 +1041,24 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // ------------------------------------------------------------------ 6 traversal + integration
 
-#ifndef NB_TR_STACK
-#define NB_TR_STACK 310
+// The stack holds one entry per opened node: {first child << 3 | child count, mask of the lanes
+// that opened it}; the (up to 4) siblings share the mask.  A round pops up to TR_ENTRIES entries
+// and gives each a group of 4 lanes: lane 4 e + i takes sibling i of the e-th entry from the top
+// (lanes past the entry's child count sit the round out).  Every visited node pushes at most one
+// entry.  Above TR_HIGH entries the wave pops one entry per round: a depth-first descent then
+// adds at most 3 entries per tree level (< 32 levels), on top of what the last full round
+// pushed, so TR_STACK - TR_HIGH >= 4 TR_ENTRIES + 3 * 32 rules out an overflow.
+#ifndef NB_TR_ENTRIES
+#define NB_TR_ENTRIES 16
 #endif
-#ifndef NB_TR_BATCH
-#define NB_TR_BATCH 36
+#ifndef NB_TR_HIGH
+#define NB_TR_HIGH 64
 #endif
-constexpr int TR_BATCH = NB_TR_BATCH;     // nodes popped and visited together (at most one per lane)
-constexpr int TR_STACK = NB_TR_STACK;     // entries per wave
-constexpr int TR_HIGH = TR_STACK - 100;   // above this the wave pops one node at a time: a
-                                          // depth-first descent adds at most 3 entries per tree
-                                          // level (< 32 levels), so the stack cannot overflow
+constexpr int TR_ENTRIES = NB_TR_ENTRIES;
+constexpr int TR_BATCH = 4 * TR_ENTRIES;  // most nodes a round can hold
+constexpr int TR_HIGH = NB_TR_HIGH;
+constexpr int TR_STACK = TR_HIGH + TR_BATCH + 3 * 32 + 1;  // entries per wave
+static_assert(TR_ENTRIES >= 1 && TR_ENTRIES <= 16, "one group of 4 lanes per popped entry");
 
 struct ForceArgs {
     const float4 *posm_s;
@@ -1158,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
         if (m0 != 0ull) {
             if (lane == 0) {
-                snode[0] = 0u;
+                snode[0] = 1u;  // the root as a group of one
                 smask[0] = m0;
             }
             top = 1;
@@ -1169,23 +1176,26 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
             n_batch += 1;
             max_top = top > max_top ? top : max_top;
         }
-        int c = top < TR_BATCH ? top : TR_BATCH;
-        int room = (TR_HIGH - top) / 3;
-        if (room < 1)
-            room = 1;
-        if (c > room)
-            c = room;
-        const int base = top - c;
+        // Pop: the group of 4 lanes e takes the e-th entry from the top, lane i of it sibling i.
+        int npop = top < TR_ENTRIES ? top : TR_ENTRIES;
+        if (top > TR_HIGH)
+            npop = 1;
+        const int grp = lane >> 2, sib = lane & 3;
         uint32_t u = 0;
         uint64_t um = 0ull;
-        if (lane < c) {
-            u = snode[base + lane];
-            um = smask[base + lane];
+        bool have = false;
+        if (grp < npop) {
+            const uint32_t ew = snode[top - 1 - grp];
+            have = (uint32_t)sib < (ew & 7u);
+            u = (ew >> 3) + (uint32_t)sib;
+            um = smask[top - 1 - grp];
         }
+        const uint64_t cmask = __builtin_amdgcn_ballot_w64(have);  // lanes holding a node
+        const int base = top - npop;
         __builtin_amdgcn_wave_barrier();
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         uint2 aux = make_uint2(0u, 0u);
-        if (lane < c) {
+        if (have) {
             rec = a.node_rec[u];
             aux = a.node_aux[u];
         }
@@ -1198,7 +1208,6 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         // the remaining cells and the bodies take the full tests.  Only cells beyond the largest
         // cutoff distance of the wave take the first two shortcuts, so neither the cutoff nor
         // the pruning rule can apply to them.
-        const uint64_t cmask = c >= 64 ? ~0ull : ((1ull << c) - 1ull);  // lanes holding an entry
         const float ex = fmaxf(fmaxf(gx0 - rec.x, rec.x - gx1), 0.f), ey = fmaxf(fmaxf(gy0 - rec.y, rec.y - gy1), 0.f);
         const float fxm = fmaxf(rec.x - gx0, gx1 - rec.x), fym = fmaxf(rec.y - gy0, gy1 - rec.y);
         const float dmin2 = __builtin_fmaf(ex, ex, ey * ey), dmax2 = __builtin_fmaf(fxm, fxm, fym * fym);
@@ -1209,22 +1218,14 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         const uint64_t farcm = farm_all & ~(openm | surem);
         const uint64_t nearm = cmask & ~(bodym | farm_all);
         if (openm != 0ull) {
-            // exclusive prefix of the child counts of the opened nodes, from the ballots of its bits
-            const uint32_t ncl = __builtin_amdgcn_inverse_ballot_w64(openm) ? (aux.x & 7u) : 0u;
-            const uint64_t b0 = __builtin_amdgcn_ballot_w64((ncl & 1u) != 0u);
-            const uint64_t b1 = __builtin_amdgcn_ballot_w64((ncl & 2u) != 0u);
-            const uint64_t b2 = __builtin_amdgcn_ballot_w64((ncl & 4u) != 0u);
-            const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
-                                 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
-                                 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
-            const uint32_t cf = aux.x >> 3;
-#pragma unroll
-            for (uint32_t i = 0; i < 4u; ++i)
-                if (i < ncl) {
-                    snode[top + off + i] = cf + i;
-                    smask[top + off + i] = um;
-                }
-            top += (int)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2));
+            // one entry per opened node that has children
+            const uint64_t pushm = openm & __builtin_amdgcn_ballot_w64((aux.x & 7u) != 0u);
+            if (__builtin_amdgcn_inverse_ballot_w64(pushm)) {
+                const int at = top + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pushm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushm, 0u));
+                snode[at] = aux.x;
+                smask[at] = um;
+            }
+            top += (int)__popcll(pushm);
             if (STATS) {
                 n_visit += (unsigned long long)__popcll(openm);
                 const uint64_t evals = __builtin_amdgcn_inverse_ballot_w64(openm) ? (uint64_t)__popcll(um) : 0ull;
@@ -1315,12 +1316,13 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                 om &= ~__builtin_amdgcn_ballot_w64(d2 < __uint_as_float(q.w));
             if (om != 0ull) {
                 const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
-                const int cf = (int)(packed >> 3), nc = (int)(packed & 7u);
-                if (lane < nc) {
-                    snode[top + lane] = (uint32_t)(cf + lane);
-                    smask[top + lane] = om;
+                if ((packed & 7u) != 0u) {
+                    if (lane == 0) {
+                        snode[top] = packed;
+                        smask[top] = om;
+                    }
+                    top += 1;
                 }
-                top += nc;
             }
 #ifdef NB_ABL_NOFORCE
             okm = 0ull;
