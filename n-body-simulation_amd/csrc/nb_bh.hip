@@ -15,7 +15,7 @@
 //   5 com      bottom-up centre of mass, FP64, children summed in the reference's order
 //              TL,TR,BL,BR (quadtree.cpp:187-228)
 //   6 force    one wave per 64 Morton-consecutive bodies; the wave shares a stack of
-//              (node, lane mask) entries in LDS, fetches up to 64 nodes per round trip, and
+//              (sibling group, lane mask) entries in LDS, fetches up to 64 nodes per round trip, and
 //              every lane applies its OWN opening test (barnesHut.cpp:70-71), so each body
 //              accepts exactly the cells the reference accepts for it.  Integration
 //              (barnesHut.cpp:108-123) is fused into the epilogue.
