@@ -215,6 +215,60 @@ __device__ __forceinline__ void run_pairs3(const Direct3Launch &a, const float4 
     }
 }
 
+typedef float v2f3 __attribute__((ext_vector_type(2)));
+
+// The cutoff-free loop on packed FP32 (v_pk_add/mul/fma_f32): targets are taken two at a time, so
+// every operation but the reciprocal square root serves two pairs.  Same operations and rounding
+// per pair as run_pairs3<.., false, ..> without the second softening term.
+template <int TPT, bool UNIFORM>
+__device__ __forceinline__ void run_pairs3_far(const Direct3Launch &a, const float4 *rec, float mu, const float (&xi)[TPT],
+                                               const float (&yi)[TPT], const float (&zi)[TPT], double (&acc)[TPT][3])
+{
+    static_assert(TPT % 2 == 0, "packed loop takes targets in pairs");
+    constexpr int P = TPT / 2;
+    const v2f3 eps2 = {a.fc.eps2, a.fc.eps2};
+    v2f3 x2[P], y2[P], z2[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        x2[p] = v2f3{xi[2 * p], xi[2 * p + 1]};
+        y2[p] = v2f3{yi[2 * p], yi[2 * p + 1]};
+        z2[p] = v2f3{zi[2 * p], zi[2 * p + 1]};
+    }
+#pragma unroll 1
+    for (int c = 0; c < DS3_SUB; c += DS3_FLUSH) {
+        v2f3 fx[P], fy[P], fz[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            fx[p] = fy[p] = fz[p] = v2f3{0.f, 0.f};
+#pragma unroll 16
+        for (int jj = 0; jj < DS3_FLUSH; ++jj) {
+            const float4 b = rec[c + jj];
+            const v2f3 bx = {b.x, b.x}, by = {b.y, b.y}, bz = {b.z, b.z}, bm = {b.w, b.w};
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const v2f3 dx = bx - x2[p], dy = by - y2[p], dz = bz - z2[p];
+                v2f3 r2 = __builtin_elementwise_fma(dx, dx, eps2);
+                r2 = __builtin_elementwise_fma(dy, dy, r2);
+                r2 = __builtin_elementwise_fma(dz, dz, r2);
+                const v2f3 rinv = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                const v2f3 s = UNIFORM ? rinv * (rinv * rinv) : (bm * rinv) * (rinv * rinv);
+                fx[p] = __builtin_elementwise_fma(dx, s, fx[p]);
+                fy[p] = __builtin_elementwise_fma(dy, s, fy[p]);
+                fz[p] = __builtin_elementwise_fma(dz, s, fz[p]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            acc[2 * p][0] += (double)(UNIFORM ? fx[p].x * mu : fx[p].x);
+            acc[2 * p + 1][0] += (double)(UNIFORM ? fx[p].y * mu : fx[p].y);
+            acc[2 * p][1] += (double)(UNIFORM ? fy[p].x * mu : fy[p].x);
+            acc[2 * p + 1][1] += (double)(UNIFORM ? fy[p].y * mu : fy[p].y);
+            acc[2 * p][2] += (double)(UNIFORM ? fz[p].x * mu : fz[p].x);
+            acc[2 * p + 1][2] += (double)(UNIFORM ? fz[p].y * mu : fz[p].y);
+        }
+    }
+}
+
 __device__ __forceinline__ float uniform_f3(float v)
 {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
@@ -327,7 +381,12 @@ __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
             const bool uni = m.mu == m.mu;
             const float4 *rec = cur + sub * DS3_SUB;
             const float *wc = wcur + sub * DS3_SUB;
-            if (far && uni)
+            if (far && !EXACT && TPT % 2 == 0) {
+                if (uni)
+                    run_pairs3_far<TPT, true>(a, rec, m.mu, xi, yi, zi, acc);
+                else
+                    run_pairs3_far<TPT, false>(a, rec, 0.f, xi, yi, zi, acc);
+            } else if (far && uni)
                 run_pairs3<TPT, EXACT, false, true>(a, rec, wc, j0, jend, m.mu, xi, yi, zi, ri, ti, acc);
             else if (far)
                 run_pairs3<TPT, EXACT, false, false>(a, rec, wc, j0, jend, 0.f, xi, yi, zi, ri, ti, acc);

@@ -315,6 +315,7 @@ def test_two_rank_partition_equals_single_rank(nb, oracle):
             p1, _, _ = r1.exchange_buffer()
             assert hip.hipMemcpy(p1, p0, chunk * rb, 3) == 0
             assert hip.hipMemcpy(p0 + chunk * rb, p1 + chunk * rb, (n - chunk) * rb, 3) == 0
+            assert hip.hipDeviceSynchronize() == 0  # the handles' streams do not wait for the null stream
             for s in (r0, r1):
                 s.step_finish()
         ref = one.read_bodies()

@@ -206,6 +206,9 @@ def test_two_rank_partition_equals_single_rank(nb, oracle):
             assert hip.hipMemcpy(p1, p0, chunk * rb, 3) == 0
             n1 = n - chunk
             assert hip.hipMemcpy(p0 + chunk * rb, p1 + chunk * rb, n1 * rb, 3) == 0
+            # a device-to-device hipMemcpy may return before the copy is done, and the handles'
+            # streams do not wait for the null stream
+            assert hip.hipDeviceSynchronize() == 0
             for s in (r0, r1):
                 s.step_finish()
         ref = one.read_bodies()
