@@ -422,3 +422,48 @@ def test_full_size_collision_properties(nb, oracle):
     ref = oracle.direct_accel_list(b, targets)
     err = rel_err(acc[targets], ref)
     assert np.median(err) < 5.0e-2 and err.max() < 1.5e-1, (np.median(err), err.max())
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_deep_clustered_tree_stresses_the_traversal_stack(nb, oracle, dims):
+    """No cutoff (so no level is closed), a small opening angle and a clump that shrinks geometrically
+    towards the origin (where float coordinates still resolve it): deep levels, many opened cells,
+    long stacks.  The stack must stay inside its
+    allocation (the kernel's bound is per construction; the counter shows the depth reached) and
+    every body must still get the oracle's acceleration."""
+    rng = np.random.default_rng(12)
+    n = 5000
+    pos = rng.uniform(-4.0e11, 4.0e11, size=(n, 3))
+    k = np.arange(n // 2)
+    scale = 4.0e11 * 2.0 ** (-(k % 14).astype(np.float64))  # the 3-D keys resolve 20 levels: keep bodies apart
+    pos[: n // 2] = scale[:, None] * rng.uniform(0.2, 1.0, size=(n // 2, 3))
+    theta, eps = 0.1, 1.0e6
+    if dims == 2:
+        from oracle_lib import make_bodies
+
+        b = make_bodies(n)
+        b["pos"] = pos[:, :2]
+    else:
+        from oracle_lib import BODY3_DTYPE
+
+        b = np.zeros(n, dtype=BODY3_DTYPE)
+        b["pos"] = pos
+    b["is_dynamic"] = 1
+    b["mass"] = rng.uniform(1.0e24, 1.0e25, size=n)
+    b["radius"] = 1.0e4
+    po = oracle.params(theta=theta, collision_th=0.0, eps=eps)
+    pn = nb.default_params(theta=theta, collision_th=0.0, eps=eps)
+    ref = oracle.bh_accel(b, po) if dims == 2 else oracle.bh_accel3(b, po)
+    Sim = nb.NBodySim if dims == 2 else nb.NBodySim3
+    with Sim(n, nb.BARNES_HUT, pn) as s:
+        s.set_bodies(b)
+        s.set_stage_timing(False, counters=True)
+        acc = s.compute_accel()
+        c = s.debug(nb.DBG_COUNTERS, np.uint64, 8)
+    assert c[3] >= 12  # tree levels
+    assert 40 < c[7] < 200  # deepest stack, entries (allocated: 225 in 2-D, 260 in 3-D)
+    # without a cutoff a body's nearest neighbours pull in all directions with terms far larger
+    # than their sum: float rounding of the terms shows in the sum of a few bodies
+    err = rel_err(acc, ref)
+    assert np.median(err) <= 5e-6 and np.quantile(err, 0.99) <= 1e-4 and err.max() <= 2e-3, (
+        np.quantile(err, [0.5, 0.99, 0.999]), err.max())
