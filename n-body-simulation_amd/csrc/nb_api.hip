@@ -95,12 +95,24 @@ int dev_alloc(T *&p, size_t count)
 
 double pow2_floor_exp(double v) { return v > 0 ? std::floor(std::log2(v)) : 0.0; }
 
-// Powers of two that bring the largest coordinate to [4, 8) and the largest mass to about 2^20.
+// The origin of the internal coordinates (the middle of the bodies' bounding box) and the powers
+// of two that bring the largest coordinate from there to [4, 8) and the largest mass to about 2^20.
 void choose_units(nb_sim *s, const nb_body *b, int n)
 {
+    double lo[2] = {b[0].position.x, b[0].position.y}, hi[2] = {lo[0], lo[1]};
+    for (int i = 1; i < n; ++i) {
+        lo[0] = std::min(lo[0], b[i].position.x);
+        hi[0] = std::max(hi[0], b[i].position.x);
+        lo[1] = std::min(lo[1], b[i].position.y);
+        hi[1] = std::max(hi[1], b[i].position.y);
+    }
+    s->units.origin[0] = 0.5 * (lo[0] + hi[0]);
+    s->units.origin[1] = 0.5 * (lo[1] + hi[1]);
+    s->units.origin[2] = 0.0;
     double maxc = 1.0, maxm = 1.0;
     for (int i = 0; i < n; ++i) {
-        maxc = std::max(maxc, std::max(std::fabs(b[i].position.x), std::fabs(b[i].position.y)));
+        maxc = std::max(maxc, std::max(std::fabs(b[i].position.x - s->units.origin[0]),
+                                       std::fabs(b[i].position.y - s->units.origin[1])));
         maxm = std::max(maxm, std::fabs(b[i].mass));
     }
     s->units.len_unit = std::ldexp(1.0, (int)pow2_floor_exp(maxc) - 2);
@@ -156,6 +168,8 @@ IntegrateArgs integrate_args(const nb_sim *s, int do_integrate)
     ia.dt = s->p.dt;
     ia.dt_kick = (s->p.integrator == NB_INT_LEAPFROG && s->first_kick) ? 0.5 * s->p.dt : s->p.dt;
     ia.inv_len_unit = 1.0 / s->units.len_unit;
+    for (int d = 0; d < 3; ++d)
+        ia.origin[d] = s->units.origin[d];
     ia.do_integrate = do_integrate;
     ia.static_fixed = (s->alg == NB_ALG_BARNES_HUT && s->p.bucket_depth > 0) ? 1 : 0;
     return ia;
@@ -224,10 +238,9 @@ int step_finish(nb_sim *s)
     if (s->alg == NB_ALG_DIRECT) {
         // records of the bodies other ranks advanced come from the gathered positions
         if (s->world > 1) {
-            const double il = 1.0 / s->units.len_unit, im = 1.0 / s->units.mass_unit;
-            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, 0, s->t0, il, im, s->p.collision_th,
+            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, 0, s->t0, s->units, s->p.collision_th,
                              s->posm[s->cur ^ 1], s->rad_s));
-            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, s->t1, s->n, il, im, s->p.collision_th,
+            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, s->t1, s->n, s->units, s->p.collision_th,
                              s->posm[s->cur ^ 1], s->rad_s));
         }
         s->cur ^= 1;
@@ -419,8 +432,7 @@ static int load_bodies(nb_sim *s, const nb_body *b, int n)
     NB_HIP(hipMemcpy(s->dyn, dyn.data(), n, hipMemcpyHostToDevice));
     if (s->alg == NB_ALG_DIRECT) {
         s->cur = 0;
-        NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, 0, n, 1.0 / s->units.len_unit, 1.0 / s->units.mass_unit,
-                         s->p.collision_th, s->posm[0], s->rad_s));
+        NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, 0, n, s->units, s->p.collision_th, s->posm[0], s->rad_s));
         NB_TRY(pad_posm(s->stream, s->posm[0], n));
         // mass and cutoff radius never change: give the second buffer the same records
         NB_HIP(hipMemcpyAsync(s->posm[1], s->posm[0], sizeof(float4) * direct_record_capacity(n),

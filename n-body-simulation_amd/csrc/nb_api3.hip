@@ -67,9 +67,21 @@ int dev_alloc(T *&p, size_t count)
 // (same rule as the 2-D path).
 void choose_units(nb_sim3 *s, const nb_body3 *b, int n)
 {
+    double lo[3] = {b[0].position.x, b[0].position.y, b[0].position.z}, hi[3] = {lo[0], lo[1], lo[2]};
+    for (int i = 1; i < n; ++i) {
+        const double p[3] = {b[i].position.x, b[i].position.y, b[i].position.z};
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = std::min(lo[d], p[d]);
+            hi[d] = std::max(hi[d], p[d]);
+        }
+    }
+    for (int d = 0; d < 3; ++d)
+        s->units.origin[d] = 0.5 * (lo[d] + hi[d]);
+    const double *o = s->units.origin;
     double maxc = 1.0, maxm = 1.0;
     for (int i = 0; i < n; ++i) {
-        maxc = std::max({maxc, std::fabs(b[i].position.x), std::fabs(b[i].position.y), std::fabs(b[i].position.z)});
+        maxc = std::max({maxc, std::fabs(b[i].position.x - o[0]), std::fabs(b[i].position.y - o[1]),
+                         std::fabs(b[i].position.z - o[2])});
         maxm = std::max(maxm, std::fabs(b[i].mass));
     }
     s->units.len_unit = std::ldexp(1.0, (int)std::floor(std::log2(maxc)) - 2);
@@ -131,6 +143,8 @@ IntegrateArgs integrate_args(const nb_sim3 *s, int do_integrate)
     ia.dt = s->p.dt;
     ia.dt_kick = (s->p.integrator == NB_INT_LEAPFROG && s->first_kick) ? 0.5 * s->p.dt : s->p.dt;
     ia.inv_len_unit = 1.0 / s->units.len_unit;
+    for (int d = 0; d < 3; ++d)
+        ia.origin[d] = s->units.origin[d];
     ia.do_integrate = do_integrate;
     ia.static_fixed = 0;
     return ia;
@@ -192,9 +206,8 @@ int step_finish(nb_sim3 *s)
     s->first_kick = false;
     if (s->alg == NB_ALG_DIRECT) {
         if (s->world > 1) {
-            const double il = 1.0 / s->units.len_unit, im = 1.0 / s->units.mass_unit;
-            NB_TRY(pack_posm3_range(s->stream, s->pos2, s->mass, 0, s->t0, il, im, s->ds.posm[s->ds.cur ^ 1]));
-            NB_TRY(pack_posm3_range(s->stream, s->pos2, s->mass, s->t1, s->n, il, im, s->ds.posm[s->ds.cur ^ 1]));
+            NB_TRY(pack_posm3_range(s->stream, s->pos2, s->mass, 0, s->t0, s->units, s->ds.posm[s->ds.cur ^ 1]));
+            NB_TRY(pack_posm3_range(s->stream, s->pos2, s->mass, s->t1, s->n, s->units, s->ds.posm[s->ds.cur ^ 1]));
         }
         s->ds.cur ^= 1;
         std::swap(s->pos, s->pos2);
@@ -283,8 +296,8 @@ int load_bodies(nb_sim3 *s, const nb_body3 *b, int n)
     NB_HIP(hipMemcpy(s->dyn, dyn.data(), n, hipMemcpyHostToDevice));
     if (s->alg == NB_ALG_DIRECT) {
         s->ds.cur = 0;
-        NB_TRY(pack_posm3(s->stream, s->pos, s->mass, s->radius, n, 1.0 / s->units.len_unit, 1.0 / s->units.mass_unit,
-                          s->p.collision_th, s->ds.posm[0], s->ds.wcut, s->ds.rad));
+        NB_TRY(pack_posm3(s->stream, s->pos, s->mass, s->radius, n, s->units, s->p.collision_th, s->ds.posm[0], s->ds.wcut,
+                          s->ds.rad));
         // masses and padding never change: the other buffer starts as a copy
         NB_HIP(hipMemcpyAsync(s->ds.posm[1], s->ds.posm[0], sizeof(float4) * direct3_record_capacity(n),
                               hipMemcpyDeviceToDevice, s->stream));

@@ -31,8 +31,12 @@ namespace nb {
 // ---- internal units ----
 // Lengths are divided by len_unit and masses by mass_unit, both powers of two, before they
 // are rounded to float: scaling by a power of two is exact, and it keeps r^3 and m/r^3 of
-// astronomical SI values (1e36, 1e-12) far from the float range limits.
+// astronomical SI values (1e36, 1e-12) far from the float range limits.  Positions are taken
+// relative to `origin` (the middle of the bodies' bounding box when they were set) first, so
+// that a system far from the coordinate origin keeps all 24 bits for its own extent; forces
+// depend on differences only.
 struct Units {
+    double origin[3];   // metres; subtracted in FP64 before scaling
     double len_unit;    // metres per internal length unit (2^k)
     double mass_unit;   // kilograms per internal mass unit (2^k)
     double acc_factor;  // multiply sum(m' d' / r'^3) by this to get m/s^2: G mass_unit / len_unit^2
@@ -52,6 +56,7 @@ struct IntegrateArgs {
     double dt;       // drift: x += v dt
     double dt_kick;  // kick: v += a dt_kick (dt, or dt/2 on the first leapfrog step)
     double inv_len_unit;
+    double origin[3];  // Units::origin
     int do_integrate;  // 0: only store accelerations
     int static_fixed;  // 1: bodies that are not dynamic keep their position and velocity
 };
@@ -74,7 +79,7 @@ size_t direct_meta_bytes(int n);
 
 // pos/mass/radius (double) -> posm records + scaled radius, bodies [i0, i1)
 int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int i0, int i1,
-              double inv_len_unit, double inv_mass_unit, double collision_th, float4 *posm, float *rad);
+              const Units &units, double collision_th, float4 *posm, float *rad);
 
 // ---- diagnostics (nb_diag.hip) ----
 // potential energy of the pairs outside the cutoff, FP64, O(n^2); *out is a device double

@@ -35,11 +35,10 @@ size_t direct3_record_capacity(int n);
 size_t direct3_meta_bytes(int n);
 int direct3_choose_jsplit(int n, int nt);
 // Fills posm[0..cap), wcut[0..cap) and rad[0..n) from the FP64 state (cap = direct3_record_capacity).
-int pack_posm3(hipStream_t s, const double *pos, const double *mass, const double *radius, int n, double inv_len_unit,
-               double inv_mass_unit, double collision_th, float4 *posm, float *wcut, float *rad);
+int pack_posm3(hipStream_t s, const double *pos, const double *mass, const double *radius, int n, const Units &units,
+               double collision_th, float4 *posm, float *wcut, float *rad);
 // Records of bodies [i0, i1) only (the ones other ranks advanced, from the gathered positions).
-int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int i0, int i1, double inv_len_unit,
-                     double inv_mass_unit, float4 *posm);
+int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int i0, int i1, const Units &units, float4 *posm);
 // One step for targets [t0, t0 + nt): reads posm[cur] and pos_cur, writes the targets' vel, acc,
 // pos_next and posm[cur ^ 1].
 int direct3_step(hipStream_t s, const Direct3State &st, int n, int t0, int nt, const ForceConsts &fc, const IntegrateArgs &ia,

@@ -152,8 +152,8 @@ __device__ __forceinline__ void integrate_one(const DirectLaunch &a, int i, doub
         p.y += v.y * a.ia.dt;
         a.vel[i] = v;
         a.pos_next[i] = p;
-        rec.x = (float)(p.x * a.ia.inv_len_unit);
-        rec.y = (float)(p.y * a.ia.inv_len_unit);
+        rec.x = (float)((p.x - a.ia.origin[0]) * a.ia.inv_len_unit);
+        rec.y = (float)((p.y - a.ia.origin[1]) * a.ia.inv_len_unit);
         a.posm_next[i] = rec;
     }
 }
@@ -478,14 +478,14 @@ __global__ __launch_bounds__(256) void k_direct_finish(DirectLaunch a)
 }
 
 __global__ __launch_bounds__(256) void k_pack_posm(const double2 *pos, const double *mass, const double *radius, int i0,
-                                                   int i1, double inv_len, double inv_mass, double cth, float4 *posm,
-                                                   float *rad)
+                                                   int i1, double ox, double oy, double inv_len, double inv_mass,
+                                                   double cth, float4 *posm, float *rad)
 {
     const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= i1)
         return;
     const double2 p = pos[i];
-    posm[i] = make_float4((float)(p.x * inv_len), (float)(p.y * inv_len), (float)(mass[i] * inv_mass),
+    posm[i] = make_float4((float)((p.x - ox) * inv_len), (float)((p.y - oy) * inv_len), (float)(mass[i] * inv_mass),
                           (float)((radius[i] + cth) * inv_len));
     rad[i] = (float)(radius[i] * inv_len);
 }
@@ -510,13 +510,13 @@ int pad_posm(hipStream_t s, float4 *posm, int n)
 }
 
 int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int i0, int i1,
-              double inv_len_unit, double inv_mass_unit, double collision_th, float4 *posm, float *rad)
+              const Units &units, double collision_th, float4 *posm, float *rad)
 {
     if (i1 <= i0)
         return NB_OK;
     const int blocks = (i1 - i0 + 255) / 256;
-    hipLaunchKernelGGL(k_pack_posm, dim3(blocks), dim3(256), 0, s, pos, mass, radius, i0, i1, inv_len_unit,
-                       inv_mass_unit, collision_th, posm, rad);
+    hipLaunchKernelGGL(k_pack_posm, dim3(blocks), dim3(256), 0, s, pos, mass, radius, i0, i1, units.origin[0],
+                       units.origin[1], 1.0 / units.len_unit, 1.0 / units.mass_unit, collision_th, posm, rad);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }

@@ -111,7 +111,7 @@ __device__ __forceinline__ void integrate_one3(const Direct3Launch &a, int i, co
             const double p = a.pos_cur[3 * (size_t)i + k] + v * a.ia.dt;
             a.vel[3 * (size_t)i + k] = v;
             a.pos_next[3 * (size_t)i + k] = p;
-            q[k] = (float)(p * a.ia.inv_len_unit);
+            q[k] = (float)((p - a.ia.origin[k]) * a.ia.inv_len_unit);
         }
         a.posm_next[i] = make_float4(q[0], q[1], q[2], rec.w);
     }
@@ -431,13 +431,13 @@ __global__ __launch_bounds__(256) void k_direct3_finish(Direct3Launch a)
 // Records of bodies [i0, i1) from the FP64 state; records [n, cap) cannot interact (zero mass,
 // far away, infinite cutoff), so whole tiles can be staged without a bounds test.
 __global__ __launch_bounds__(256) void k_pack_posm3(const double *pos, const double *mass, const double *radius, int i0, int i1,
-                                                    int n, int cap, double inv_len, double inv_mass, double cth, float4 *posm,
-                                                    float *wcut, float *rad)
+                                                    int n, int cap, double ox, double oy, double oz, double inv_len,
+                                                    double inv_mass, double cth, float4 *posm, float *wcut, float *rad)
 {
     const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i < i1 && i < n) {
-        posm[i] = make_float4((float)(pos[3 * (size_t)i] * inv_len), (float)(pos[3 * (size_t)i + 1] * inv_len),
-                              (float)(pos[3 * (size_t)i + 2] * inv_len), (float)(mass[i] * inv_mass));
+        posm[i] = make_float4((float)((pos[3 * (size_t)i] - ox) * inv_len), (float)((pos[3 * (size_t)i + 1] - oy) * inv_len),
+                              (float)((pos[3 * (size_t)i + 2] - oz) * inv_len), (float)(mass[i] * inv_mass));
         wcut[i] = (float)((radius[i] + cth) * inv_len);
         rad[i] = (float)(radius[i] * inv_len);
     } else if (i >= n && i < cap) {
@@ -449,12 +449,13 @@ __global__ __launch_bounds__(256) void k_pack_posm3(const double *pos, const dou
 size_t direct3_record_capacity(int n) { return ((size_t)n + DS3_TILE - 1) / DS3_TILE * DS3_TILE + DS3_TILE; }
 size_t direct3_meta_bytes(int n) { return sizeof(SubMeta3) * (size_t)((n + DS3_SUB - 1) / DS3_SUB); }
 
-int pack_posm3(hipStream_t s, const double *pos, const double *mass, const double *radius, int n, double inv_len_unit,
-               double inv_mass_unit, double collision_th, float4 *posm, float *wcut, float *rad)
+int pack_posm3(hipStream_t s, const double *pos, const double *mass, const double *radius, int n, const Units &units,
+               double collision_th, float4 *posm, float *wcut, float *rad)
 {
     const int cap = (int)direct3_record_capacity(n);
-    hipLaunchKernelGGL(k_pack_posm3, dim3((cap + 255) / 256), dim3(256), 0, s, pos, mass, radius, 0, cap, n, cap, inv_len_unit,
-                       inv_mass_unit, collision_th, posm, wcut, rad);
+    hipLaunchKernelGGL(k_pack_posm3, dim3((cap + 255) / 256), dim3(256), 0, s, pos, mass, radius, 0, cap, n, cap,
+                       units.origin[0], units.origin[1], units.origin[2], 1.0 / units.len_unit, 1.0 / units.mass_unit,
+                       collision_th, posm, wcut, rad);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -474,22 +475,21 @@ int direct3_choose_jsplit(int n, int nt)
     return want < 1 ? 1 : want;
 }
 
-__global__ __launch_bounds__(256) void k_pack_posm3_range(const double *pos, const double *mass, int i0, int i1, double inv_len,
-                                                          double inv_mass, float4 *posm)
+__global__ __launch_bounds__(256) void k_pack_posm3_range(const double *pos, const double *mass, int i0, int i1, double ox,
+                                                          double oy, double oz, double inv_len, double inv_mass, float4 *posm)
 {
     const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i < i1)
-        posm[i] = make_float4((float)(pos[3 * (size_t)i] * inv_len), (float)(pos[3 * (size_t)i + 1] * inv_len),
-                              (float)(pos[3 * (size_t)i + 2] * inv_len), (float)(mass[i] * inv_mass));
+        posm[i] = make_float4((float)((pos[3 * (size_t)i] - ox) * inv_len), (float)((pos[3 * (size_t)i + 1] - oy) * inv_len),
+                              (float)((pos[3 * (size_t)i + 2] - oz) * inv_len), (float)(mass[i] * inv_mass));
 }
 
-int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int i0, int i1, double inv_len_unit,
-                     double inv_mass_unit, float4 *posm)
+int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int i0, int i1, const Units &units, float4 *posm)
 {
     if (i1 <= i0)
         return NB_OK;
-    hipLaunchKernelGGL(k_pack_posm3_range, dim3((i1 - i0 + 255) / 256), dim3(256), 0, s, pos, mass, i0, i1, inv_len_unit,
-                       inv_mass_unit, posm);
+    hipLaunchKernelGGL(k_pack_posm3_range, dim3((i1 - i0 + 255) / 256), dim3(256), 0, s, pos, mass, i0, i1, units.origin[0],
+                       units.origin[1], units.origin[2], 1.0 / units.len_unit, 1.0 / units.mass_unit, posm);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }

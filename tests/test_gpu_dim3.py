@@ -311,3 +311,32 @@ def test_argument_checks(nb):
             s.update()
         with pytest.raises(nb.NBodyError):
             s.set_bodies(np.zeros(7, dtype=nb.BODY3_DTYPE))
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_a_system_far_from_the_coordinate_origin_keeps_its_precision(nb, oracle, dims):
+    """Float coordinates are taken relative to the middle of the bodies' bounding box: moving the
+    whole system by 60 times its size must not cost accuracy (the oracle works in FP64)."""
+    n = 3000
+    shift = np.array([3.0e13, -2.0e13, 1.0e13])
+    if dims == 2:
+        b = oracle.scenario(0, n, 6)
+        b["pos"] += shift[:2]
+        refs = (oracle.direct_accel(b), oracle.bh_accel(b))
+        Sim = nb.NBodySim
+    else:
+        b = oracle.scenario3(0, n, 6, thickness=5.0e10)
+        b["pos"] += shift
+        refs = (oracle.direct_accel3(b), oracle.bh_accel3(b))
+        Sim = nb.NBodySim3
+    for alg, ref, tol in ((nb.DIRECT, refs[0], DS_TOL), (nb.BARNES_HUT, refs[1], BH_TOL)):
+        with Sim(n, alg) as s:
+            s.set_bodies(b)
+            acc = s.compute_accel()
+            assert rel_err(acc, ref).max() <= tol, (dims, alg, rel_err(acc, ref).max())
+            # and after a few steps (the records of moved bodies are refreshed relative to the same origin)
+            s.update(3)
+            out = s.read_bodies()
+        step = {(2, 0): oracle.direct_step, (2, 1): oracle.bh_step, (3, 0): oracle.direct_step3, (3, 1): oracle.bh_step3}[(dims, alg)]
+        want = step(b, 3)
+        assert np.abs(out["pos"] - want["pos"]).max() <= 1e-7 * 5e11

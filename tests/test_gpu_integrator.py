@@ -47,7 +47,13 @@ def test_leapfrog_matches_kdk(nb, oracle, alg, name):
     assert np.abs(got["pos"] - want["pos"]).max() / scale < 1e-6
     vscale = np.abs(want["vel"]).max()
     assert np.abs(got["vel"] - want["vel"]).max() / vscale < 1e-4  # FP32 forces accumulate in velocities
-    assert rel_err(got["acc"], want["acc"]).max() < (1e-5 if alg == "direct" else 1e-4)
+    # the accelerations returned are those of the positions returned: compare there, so that the
+    # small difference of the two trajectories does not count as a force error
+    at = got.copy()
+    ref_acc = accel(at)
+    ref_acc[b0["is_dynamic"] == 0] = 0.0
+    err = rel_err(got["acc"], ref_acc).max()
+    assert err < (1e-5 if alg == "direct" else 1e-4), err
 
 
 def test_leapfrog_read_does_not_disturb_the_run(nb):
