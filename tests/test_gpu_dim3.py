@@ -340,3 +340,51 @@ def test_a_system_far_from_the_coordinate_origin_keeps_its_precision(nb, oracle,
         step = {(2, 0): oracle.direct_step, (2, 1): oracle.bh_step, (3, 0): oracle.direct_step3, (3, 1): oracle.bh_step3}[(dims, alg)]
         want = step(b, 3)
         assert np.abs(out["pos"] - want["pos"]).max() <= 1e-7 * 5e11
+
+
+@pytest.mark.parametrize("alg", [0, 1])
+@pytest.mark.parametrize("n", [1, 2, 3, 65, 129])
+def test_tiny_systems(nb, oracle, alg, n):
+    rng = np.random.default_rng(n)
+    b = np.zeros(n, dtype=nb.BODY3_DTYPE)
+    b["is_dynamic"] = 1
+    b["mass"] = rng.uniform(1e24, 1e26, n)
+    b["radius"] = 1.0e4
+    b["pos"] = rng.uniform(-3e11, 3e11, (n, 3))
+    b["vel"] = rng.uniform(-1e3, 1e3, (n, 3))
+    ref = oracle.direct_accel3(b) if alg == 0 else oracle.bh_accel3(b)
+    with nb.NBodySim3(n, alg) as s:
+        s.set_bodies(b)
+        acc = s.compute_accel()
+        s.update(2)
+        out = s.read_bodies()
+    assert rel_err(acc, ref).max() <= (DS_TOL if alg == 0 else BH_TOL)
+    want = (oracle.direct_step3 if alg == 0 else oracle.bh_step3)(b, 2)
+    assert np.abs(out["pos"] - want["pos"]).max() <= 1e-9 * 5e11
+
+
+@pytest.mark.parametrize("alg", [0, 1])
+def test_coincident_and_static_bodies(nb, oracle, alg):
+    """Two bodies at one point (the reference's tree would recurse without end; they are inside each
+    other's cutoff, so they exert nothing on each other) and a static body that must not move."""
+    b = oracle.scenario3(1, 400, 13, thickness=1.0e11)
+    b["pos"][7] = b["pos"][3]
+    b["pos"][11] = b["pos"][3]
+    b["is_dynamic"][20] = 0
+    b["acc"][20] = [1.0e-9, -2.0e-9, 3.0e-9]  # a static body keeps the acceleration it was given ...
+    b["vel"][20] = [5.0, 0.0, -5.0]           # ... and moves with its own velocity
+    ref = oracle.direct_accel3(b)             # the pairs inside the cutoff drop out of both sums
+    with nb.NBodySim3(len(b), alg) as s:
+        s.set_bodies(b)
+        acc = s.compute_accel()
+        s.update(1)
+        out = s.read_bodies()
+    dyn = b["is_dynamic"] != 0
+    tol = DS_TOL if alg == 0 else 2e-2  # Barnes-Hut against the direct sum: the tree's own error
+    assert rel_err(acc[dyn], ref[dyn]).max() <= tol
+    if alg == 0:
+        assert not out["acc"][20].any()       # DirectSum::calculateAcceleration zeroes static bodies
+    else:
+        assert np.array_equal(out["acc"][20], b["acc"][20])
+        assert np.allclose(out["vel"][20], b["vel"][20] + 25000.0 * b["acc"][20], rtol=1e-15)
+    assert np.all(np.isfinite(out["pos"]))
