@@ -329,7 +329,8 @@ int read_state(nb_sim3 *s, nb_body3 *out, double half_kick)
         x.radius = radius[k];
         const double *p = &pos[3 * (size_t)k], *v = &vel[3 * (size_t)k], *a = &acc[3 * (size_t)k];
         x.position = {p[0], p[1], p[2]};
-        x.velocity = {v[0] + half_kick * a[0], v[1] + half_kick * a[1], v[2] + half_kick * a[2]};
+        const double hk = (k >= s->t0 && k < s->t1) ? half_kick : 0.0;  // other ranks' velocities are not held here
+        x.velocity = {v[0] + hk * a[0], v[1] + hk * a[1], v[2] + hk * a[2]};
         x.acceleration = {a[0], a[1], a[2]};
     }
     return NB_OK;
