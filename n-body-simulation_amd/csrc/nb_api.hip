@@ -14,6 +14,7 @@
 
 #include "nb_bh.h"
 #include "nb_common.h"
+#include "nb_timing.h"
 
 namespace nb {
 
@@ -71,13 +72,7 @@ struct nb_sim {
     BhBuffers bh;
     int collect_stats = 0;
 
-    // stage timing
-    int timing = 0;
-    static constexpr int TIMING_RING = 32;  // steps whose events may be pending before the host waits
-    hipEvent_t ev[TIMING_RING][8] = {};
-    int ev_used = 0;          // event sets recorded and not yet read
-    double stage_sum[8] = {};  // milliseconds per stage summed over stage_steps steps
-    int stage_steps = 0;
+    StageTimer timer;
 };
 
 namespace {
@@ -199,11 +194,7 @@ BhStepArgs bh_args(nb_sim *s, int do_integrate)
     return a;
 }
 
-void mark(nb_sim *s, int k)
-{
-    if (s->timing)
-        (void)hipEventRecord(s->ev[s->ev_used][k], s->stream);
-}
+void mark(nb_sim *s, int k) { s->timer.mark(s->stream, k); }
 
 int step_local(nb_sim *s, int do_integrate)
 {
@@ -249,34 +240,7 @@ int step_finish(nb_sim *s)
     return NB_OK;
 }
 
-// Reads the event sets recorded so far into the per-stage sums (waits for the stream).
-int drain_timing(nb_sim *s)
-{
-    if (s->ev_used == 0)
-        return NB_OK;
-    NB_HIP(hipStreamSynchronize(s->stream));
-    const int last = s->alg == NB_ALG_DIRECT ? 1 : 6;
-    for (int e = 0; e < s->ev_used; ++e) {
-        for (int k = 0; k < last; ++k) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, s->ev[e][k], s->ev[e][k + 1]) == hipSuccess)
-                s->stage_sum[s->alg == NB_ALG_DIRECT ? 5 : k] += ms;
-        }
-        s->stage_steps += 1;
-    }
-    s->ev_used = 0;
-    return NB_OK;
-}
-
-// A step's events are recorded: nothing is waited for until the ring is full or the caller asks.
-int collect_timing(nb_sim *s)
-{
-    if (!s->timing)
-        return NB_OK;
-    if (++s->ev_used == nb_sim::TIMING_RING)
-        return drain_timing(s);
-    return NB_OK;
-}
+int collect_timing(nb_sim *s) { return s->timer.step_done(s->stream, s->alg == NB_ALG_DIRECT); }
 
 void release(nb_sim *s)
 {
@@ -293,10 +257,7 @@ void release(nb_sim *s)
     (void)hipFree(s->part);
     (void)hipFree(s->ds_meta);
     bh_free(s->bh);
-    for (auto &set : s->ev)
-        for (auto &e : set)
-            if (e)
-                (void)hipEventDestroy(e);
+    s->timer.destroy();
     if (s->own_stream && s->stream)
         (void)hipStreamDestroy(s->stream);
 }
@@ -371,10 +332,8 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
     } else {
         chk(bh_alloc(s->bh, n));
     }
-    for (auto &set : s->ev)
-        for (auto &e : set)
-            if (rc == NB_OK && hipEventCreate(&e) != hipSuccess)
-                chk(fail(NB_ERR_HIP, "hipEventCreate failed"));
+    if (rc == NB_OK)
+        chk(s->timer.create());
     if (rc != NB_OK) {
         release(s);
         delete s;
@@ -703,26 +662,15 @@ int nb_set_stage_timing(nb_sim *s, int on)
 {
     if (!s)
         return fail(NB_ERR_ARG, "nb_set_stage_timing: sim is NULL");
-    NB_TRY(drain_timing(s));
-    s->timing = (on & 1) ? 1 : 0;
     s->collect_stats = (on & 2) ? 1 : 0;
-    for (double &v : s->stage_sum)
-        v = 0.0;
-    s->stage_steps = 0;
-    return NB_OK;
+    return s->timer.set(s->stream, s->alg == NB_ALG_DIRECT, on & 1);
 }
 
 int nb_stage_ms(nb_sim *s, float *out, int count)
 {
     if (!s || !out)
         return fail(NB_ERR_ARG, "nb_stage_ms: NULL argument");
-    NB_TRY(drain_timing(s));
-    for (int k = 0; k < count; ++k)
-        out[k] = (k < 8 && s->stage_steps > 0) ? (float)(s->stage_sum[k] / s->stage_steps) : 0.f;
-    for (double &v : s->stage_sum)
-        v = 0.0;
-    s->stage_steps = 0;
-    return NB_OK;
+    return s->timer.read(s->stream, s->alg == NB_ALG_DIRECT, out, count);
 }
 
 int nb_debug_read(nb_sim *s, int which, void *out, size_t bytes, size_t *written)

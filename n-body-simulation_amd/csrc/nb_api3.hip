@@ -9,6 +9,7 @@
 
 #include "nb_bh.h"
 #include "nb_common.h"
+#include "nb_timing.h"
 #include "nb_dim3.h"
 
 using namespace nb;
@@ -42,12 +43,7 @@ struct nb_sim3 {
     Bh3Buffers bh;
     int collect_stats = 0;
 
-    int timing = 0;
-    static constexpr int TIMING_RING = 32;
-    hipEvent_t ev[TIMING_RING][8] = {};
-    int ev_used = 0;
-    double stage_sum[8] = {};
-    int stage_steps = 0;
+    StageTimer timer;
 };
 
 namespace {
@@ -150,11 +146,7 @@ IntegrateArgs integrate_args(const nb_sim3 *s, int do_integrate)
     return ia;
 }
 
-void mark(nb_sim3 *s, int k)
-{
-    if (s->timing)
-        (void)hipEventRecord(s->ev[s->ev_used][k], s->stream);
-}
+void mark(nb_sim3 *s, int k) { s->timer.mark(s->stream, k); }
 
 int step_local(nb_sim3 *s, int do_integrate)
 {
@@ -215,32 +207,7 @@ int step_finish(nb_sim3 *s)
     return NB_OK;
 }
 
-int drain_timing(nb_sim3 *s)
-{
-    if (s->ev_used == 0)
-        return NB_OK;
-    NB_HIP(hipStreamSynchronize(s->stream));
-    const int last = s->alg == NB_ALG_DIRECT ? 1 : 6;
-    for (int e = 0; e < s->ev_used; ++e) {
-        for (int k = 0; k < last; ++k) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, s->ev[e][k], s->ev[e][k + 1]) == hipSuccess)
-                s->stage_sum[s->alg == NB_ALG_DIRECT ? 5 : k] += ms;
-        }
-        s->stage_steps += 1;
-    }
-    s->ev_used = 0;
-    return NB_OK;
-}
-
-int collect_timing(nb_sim3 *s)
-{
-    if (!s->timing)
-        return NB_OK;
-    if (++s->ev_used == nb_sim3::TIMING_RING)
-        return drain_timing(s);
-    return NB_OK;
-}
+int collect_timing(nb_sim3 *s) { return s->timer.step_done(s->stream, s->alg == NB_ALG_DIRECT); }
 
 void release(nb_sim3 *s)
 {
@@ -258,10 +225,7 @@ void release(nb_sim3 *s)
     (void)hipFree(s->ds.part);
     (void)hipFree(s->ds.meta);
     bh3_free(s->bh);
-    for (auto &set : s->ev)
-        for (auto &e : set)
-            if (e)
-                (void)hipEventDestroy(e);
+    s->timer.destroy();
     if (s->own_stream && s->stream)
         (void)hipStreamDestroy(s->stream);
 }
@@ -403,10 +367,8 @@ int nb3_create(const nb_params *params, int n, int alg, nb_sim3 **out)
     } else {
         chk(bh3_alloc(s->bh, n));
     }
-    for (auto &set : s->ev)
-        for (auto &e : set)
-            if (rc == NB_OK && hipEventCreate(&e) != hipSuccess)
-                chk(fail(NB_ERR_HIP, "hipEventCreate failed"));
+    if (rc == NB_OK)
+        chk(s->timer.create());
     if (rc != NB_OK) {
         release(s);
         delete s;
@@ -635,26 +597,15 @@ int nb3_set_stage_timing(nb_sim3 *s, int on)
 {
     if (!s)
         return fail(NB_ERR_ARG, "nb3_set_stage_timing: sim is NULL");
-    NB_TRY(drain_timing(s));
-    s->timing = (on & 1) ? 1 : 0;
     s->collect_stats = (on & 2) ? 1 : 0;
-    for (double &v : s->stage_sum)
-        v = 0.0;
-    s->stage_steps = 0;
-    return NB_OK;
+    return s->timer.set(s->stream, s->alg == NB_ALG_DIRECT, on & 1);
 }
 
 int nb3_stage_ms(nb_sim3 *s, float *out, int count)
 {
     if (!s || !out)
         return fail(NB_ERR_ARG, "nb3_stage_ms: NULL argument");
-    NB_TRY(drain_timing(s));
-    for (int k = 0; k < count; ++k)
-        out[k] = (k < 8 && s->stage_steps > 0) ? (float)(s->stage_sum[k] / s->stage_steps) : 0.f;
-    for (double &v : s->stage_sum)
-        v = 0.0;
-    s->stage_steps = 0;
-    return NB_OK;
+    return s->timer.read(s->stream, s->alg == NB_ALG_DIRECT, out, count);
 }
 
 int nb3_debug_read(nb_sim3 *s, int which, void *out, size_t bytes, size_t *written)

@@ -1,0 +1,101 @@
+// nb_timing.h -- per-stage timing with HIP events, shared by the 2-D and 3-D handles.
+//
+// A step records up to 7 events on the simulation's stream (stage k lies between marks k and
+// k + 1) without waiting for anything; the host only waits when RING steps are pending or when
+// the caller asks for the numbers, which are means over the steps since the previous query.
+#pragma once
+
+#include "nb_common.h"
+
+namespace nb {
+
+struct StageTimer {
+    static constexpr int RING = 32;  // steps whose events may be pending before the host waits
+    int on = 0;
+    hipEvent_t ev[RING][8] = {};
+    int used = 0;       // event sets recorded and not yet read
+    double sum[8] = {};  // milliseconds per stage summed over `steps` steps
+    int steps = 0;
+
+    int create()
+    {
+        for (auto &set : ev)
+            for (auto &e : set)
+                if (hipEventCreate(&e) != hipSuccess)
+                    return fail(NB_ERR_HIP, "hipEventCreate failed");
+        return NB_OK;
+    }
+
+    void destroy()
+    {
+        for (auto &set : ev)
+            for (auto &e : set)
+                if (e) {
+                    (void)hipEventDestroy(e);
+                    e = nullptr;
+                }
+    }
+
+    void mark(hipStream_t stream, int k)
+    {
+        if (on)
+            (void)hipEventRecord(ev[used][k], stream);
+    }
+
+    // Reads the event sets recorded so far into the sums (waits for the stream).  A direct-sum
+    // step has one stage (marks 0 and 1), reported as stage 5; Barnes-Hut has stages 0..5.
+    int drain(hipStream_t stream, bool direct)
+    {
+        if (used == 0)
+            return NB_OK;
+        NB_HIP(hipStreamSynchronize(stream));
+        const int last = direct ? 1 : 6;
+        for (int e = 0; e < used; ++e) {
+            for (int k = 0; k < last; ++k) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev[e][k], ev[e][k + 1]) == hipSuccess)
+                    sum[direct ? 5 : k] += ms;
+            }
+            steps += 1;
+        }
+        used = 0;
+        return NB_OK;
+    }
+
+    // A step's events are recorded: nothing is waited for until the ring is full.
+    int step_done(hipStream_t stream, bool direct)
+    {
+        if (!on)
+            return NB_OK;
+        if (++used == RING)
+            return drain(stream, direct);
+        return NB_OK;
+    }
+
+    void reset()
+    {
+        for (double &v : sum)
+            v = 0.0;
+        steps = 0;
+    }
+
+    int set(hipStream_t stream, bool direct, int enable)
+    {
+        NB_TRY(drain(stream, direct));
+        on = enable ? 1 : 0;
+        reset();
+        return NB_OK;
+    }
+
+    // Mean milliseconds per stage since the previous call; starts a new average.
+    int read(hipStream_t stream, bool direct, float *out, int count)
+    {
+        NB_TRY(drain(stream, direct));
+        for (int k = 0; k < count; ++k)
+            out[k] = (k < 8 && steps > 0) ? (float)(sum[k] / steps) : 0.f;
+        reset();
+        return NB_OK;
+    }
+};
+
+}  // namespace nb
