@@ -77,17 +77,6 @@ struct nb_sim {
 
 namespace {
 
-template <typename T>
-int dev_alloc(T *&p, size_t count)
-{
-    void *v = nullptr;
-    hipError_t e = hipMalloc(&v, count * sizeof(T) + 256);
-    if (e != hipSuccess)
-        return fail(NB_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    p = (T *)v;
-    return NB_OK;
-}
-
 double pow2_floor_exp(double v) { return v > 0 ? std::floor(std::log2(v)) : 0.0; }
 
 // The origin of the internal coordinates (the middle of the bodies' bounding box) and the powers

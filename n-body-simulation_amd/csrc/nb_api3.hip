@@ -48,17 +48,6 @@ struct nb_sim3 {
 
 namespace {
 
-template <typename T>
-int dev_alloc(T *&p, size_t count)
-{
-    void *v = nullptr;
-    hipError_t e = hipMalloc(&v, count * sizeof(T) + 256);
-    if (e != hipSuccess)
-        return fail(NB_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    p = (T *)v;
-    return NB_OK;
-}
-
 // Powers of two that bring the largest coordinate to [4, 8) and the largest mass to about 2^20
 // (same rule as the 2-D path).
 void choose_units(nb_sim3 *s, const nb_body3 *b, int n)

@@ -1586,17 +1586,6 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // ------------------------------------------------------------------ buffers
 
-template <typename T>
-static int dev_alloc(T *&p, size_t count)
-{
-    void *v = nullptr;
-    hipError_t e = hipMalloc(&v, count * sizeof(T) + 256);
-    if (e != hipSuccess)
-        return fail(NB_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    p = (T *)v;
-    return NB_OK;
-}
-
 int bh_alloc(BhBuffers &b, int n)
 {
     b.n = n;

@@ -867,48 +867,37 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
 
 // ------------------------------------------------------------------ buffers
 
-template <typename T>
-static int dev_alloc3(T *&p, size_t count)
-{
-    void *v = nullptr;
-    hipError_t e = hipMalloc(&v, count * sizeof(T) + 256);
-    if (e != hipSuccess)
-        return fail(NB_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    p = (T *)v;
-    return NB_OK;
-}
-
 int bh3_alloc(Bh3Buffers &b, int n)
 {
     b.n = n;
     b.node_cap = 2 * (size_t)n + 8;
-    NB_TRY(dev_alloc3(b.box, 6));
-    NB_TRY(dev_alloc3(b.cut, 4));
-    NB_TRY(dev_alloc3(b.bbox_part, 6 * BBOX3_BLOCKS));
+    NB_TRY(dev_alloc(b.box, 6));
+    NB_TRY(dev_alloc(b.cut, 4));
+    NB_TRY(dev_alloc(b.bbox_part, 6 * BBOX3_BLOCKS));
     for (int k = 0; k < 2; ++k) {
-        NB_TRY(dev_alloc3(b.keys[k], (size_t)n));
-        NB_TRY(dev_alloc3(b.idx[k], (size_t)n));
+        NB_TRY(dev_alloc(b.keys[k], (size_t)n));
+        NB_TRY(dev_alloc(b.idx[k], (size_t)n));
     }
-    NB_TRY(dev_alloc3(b.hist, sort_hist_words(n)));
-    NB_TRY(dev_alloc3(b.hist_totals, 256));
-    NB_TRY(dev_alloc3(b.leaf_sum, 6 * (size_t)n));
-    NB_TRY(dev_alloc3(b.posm_s, (size_t)n));
-    NB_TRY(dev_alloc3(b.rad_s, (size_t)n));
-    NB_TRY(dev_alloc3(b.node_meta, b.node_cap));
+    NB_TRY(dev_alloc(b.hist, sort_hist_words(n)));
+    NB_TRY(dev_alloc(b.hist_totals, 256));
+    NB_TRY(dev_alloc(b.leaf_sum, 6 * (size_t)n));
+    NB_TRY(dev_alloc(b.posm_s, (size_t)n));
+    NB_TRY(dev_alloc(b.rad_s, (size_t)n));
+    NB_TRY(dev_alloc(b.node_meta, b.node_cap));
     {
         uint8_t *sp = nullptr;
-        NB_TRY(dev_alloc3(sp, ((size_t)n + 256) * build_split_bytes(3)));
+        NB_TRY(dev_alloc(sp, ((size_t)n + 256) * build_split_bytes(3)));
         b.split = sp;
     }
-    NB_TRY(dev_alloc3(b.level_start, BH_MAX_DEPTH + 2));
-    NB_TRY(dev_alloc3(b.bsum, BH_SCAN_BLOCKS));
-    NB_TRY(dev_alloc3(b.node_com, 6 * b.node_cap));
-    NB_TRY(dev_alloc3(b.node_rec, b.node_cap));
-    NB_TRY(dev_alloc3(b.node_aux, b.node_cap));
-    NB_TRY(dev_alloc3(b.tlist, (size_t)n));
-    NB_TRY(dev_alloc3(b.tcount, 4));
-    NB_TRY(dev_alloc3(b.tblock, target_list_blocks(n)));
-    NB_TRY(dev_alloc3(b.counters, 8));
+    NB_TRY(dev_alloc(b.level_start, BH_MAX_DEPTH + 2));
+    NB_TRY(dev_alloc(b.bsum, BH_SCAN_BLOCKS));
+    NB_TRY(dev_alloc(b.node_com, 6 * b.node_cap));
+    NB_TRY(dev_alloc(b.node_rec, b.node_cap));
+    NB_TRY(dev_alloc(b.node_aux, b.node_cap));
+    NB_TRY(dev_alloc(b.tlist, (size_t)n));
+    NB_TRY(dev_alloc(b.tcount, 4));
+    NB_TRY(dev_alloc(b.tblock, target_list_blocks(n)));
+    NB_TRY(dev_alloc(b.counters, 8));
     void *h = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
         return fail(NB_ERR_NOMEM, "hipHostMalloc failed");

@@ -28,6 +28,19 @@ namespace nb {
             return nb_rc_;      \
     } while (0)
 
+// Device array of `count` elements (plus a little slack, so that a kernel may read one vector
+// past the end of the last element it needs).
+template <typename T>
+inline int dev_alloc(T *&p, size_t count)
+{
+    void *v = nullptr;
+    hipError_t e = hipMalloc(&v, count * sizeof(T) + 256);
+    if (e != hipSuccess)
+        return fail(NB_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    p = (T *)v;
+    return NB_OK;
+}
+
 // ---- internal units ----
 // Lengths are divided by len_unit and masses by mass_unit, both powers of two, before they
 // are rounded to float: scaling by a power of two is exact, and it keeps r^3 and m/r^3 of
