@@ -85,6 +85,7 @@ int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], i
 // (n + 256) * build_split_bytes(bits) bytes; level_start: BH_MAX_DEPTH + 2 words; bsum:
 // BH_SCAN_BLOCKS words; counters: 8 words, zeroed here.
 size_t build_split_bytes(int bits);
+int level_blocks(int d, int bits, int nodes_per_block);  // grid of a per-level kernel (<= BH_SCAN_BLOCKS)
 int launched_levels(const uint32_t *levels_host);
 int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node_meta, void *split, uint32_t *level_start,
                uint32_t *bsum, unsigned long long *counters, int launched);

@@ -439,14 +439,14 @@ __global__ void k_build_init(uint4 *node_meta, uint32_t *level_start, int n, uns
 // 64 or 8 positions per round instead of one.
 __device__ __forceinline__ int search_group(uint32_t m) { return m <= 4096u ? 64 : (m <= 65536u ? 8 : 1); }
 
-// Slots of tree level d are dealt to the BH_SCAN_BLOCKS blocks in contiguous chunks (multiples
+// Slots of tree level d are dealt to the grid's blocks in contiguous chunks (multiples
 // of 256 where a thread has a node to itself), the same way in the count and in the emit kernel.
 __device__ __forceinline__ void level_chunk(const uint32_t *level_start, int d, uint32_t &lbeg, uint32_t &m,
                                             uint32_t &cbeg, uint32_t &cend)
 {
     lbeg = level_start[d];
     m = level_start[d + 1] - lbeg;
-    uint32_t chunk = (m + BH_SCAN_BLOCKS - 1) / BH_SCAN_BLOCKS;
+    uint32_t chunk = (m + gridDim.x - 1) / gridDim.x;
     if (search_group(m) == 1)
         chunk = (chunk + 255u) & ~255u;
     cbeg = blockIdx.x * chunk;
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, const Spli
     level_chunk(level_start, d, lbeg, m, cbeg, cend);
     // children allocated by the blocks before this one, and by the whole level
     int before = 0, all = 0;
-    for (int k = threadIdx.x; k < BH_SCAN_BLOCKS; k += 256) {
+    for (int k = threadIdx.x; k < (int)gridDim.x; k += 256) {
         int v = (int)bsum[k];
         all += v;
         if (k < (int)blockIdx.x)
@@ -735,15 +735,28 @@ int launched_levels(const uint32_t *levels_host)
 
 size_t build_split_bytes(int bits) { return bits == 3 ? sizeof(Split<3>) : sizeof(Split<2>); }
 
+// Blocks for a per-level kernel of tree level d: the level holds at most 2^(bits d) nodes, and a
+// kernel over a handful of nodes finishes sooner when it does not dispatch a thousand idle blocks.
+int level_blocks(int d, int bits, int nodes_per_block)
+{
+    const int shift = bits * d;
+    if (shift >= 20)
+        return BH_SCAN_BLOCKS;
+    const int nodes = 1 << shift;
+    const int blocks = (nodes + nodes_per_block - 1) / nodes_per_block;
+    return blocks < BH_SCAN_BLOCKS ? blocks : BH_SCAN_BLOCKS;
+}
+
 template <int BITS>
 static void launch_build(hipStream_t s, const uint64_t *keys, int n, uint4 *node_meta, void *split, uint32_t *level_start,
                          uint32_t *bsum, unsigned long long *counters, int launched)
 {
     hipLaunchKernelGGL(k_build_init, dim3(1), dim3(64), 0, s, node_meta, level_start, n, counters);
     for (int d = 0; d < launched; ++d) {
-        hipLaunchKernelGGL(k_build_count<BITS>, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, keys, node_meta, (Split<BITS> *)split,
+        const dim3 grid(level_blocks(d, BITS, 4));  // 4 nodes per block while a wave searches for each node
+        hipLaunchKernelGGL(k_build_count<BITS>, grid, dim3(256), 0, s, keys, node_meta, (Split<BITS> *)split,
                            level_start, bsum, d);
-        hipLaunchKernelGGL(k_build_emit<BITS>, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, node_meta,
+        hipLaunchKernelGGL(k_build_emit<BITS>, grid, dim3(256), 0, s, node_meta,
                            (const Split<BITS> *)split, level_start, bsum, d);
     }
     hipLaunchKernelGGL(k_build_tail<BITS>, dim3(1), dim3(256), 0, s, keys, node_meta, level_start, launched);
@@ -1039,7 +1052,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
     for (int d = b.launched - 1; d >= 0; --d)
-        hipLaunchKernelGGL(k_com, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, c, d, d + 1);
+        hipLaunchKernelGGL(k_com, dim3(level_blocks(d, 2, 256)), dim3(256), 0, s, c, d, d + 1);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }

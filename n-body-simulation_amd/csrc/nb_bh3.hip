@@ -438,7 +438,7 @@ int bh3_com(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com3, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
     for (int d = b.launched - 1; d >= 0; --d)
-        hipLaunchKernelGGL(k_com3, dim3(BH_SCAN_BLOCKS), dim3(256), 0, s, c, d, d + 1);
+        hipLaunchKernelGGL(k_com3, dim3(level_blocks(d, 3, 256)), dim3(256), 0, s, c, d, d + 1);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
