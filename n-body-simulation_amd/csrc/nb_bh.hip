@@ -795,7 +795,9 @@ struct ComArgs {
     uint2 *node_aux;
     const uint32_t *cut;
     const double *leaf_sum;  // per sorted position: sums of the run of equal keys that starts there
-    double ox, oy;  // origin of the float coordinates
+    // The float coordinates of a step are taken relative to the middle of that step's bounding
+    // box (a.box): every kernel of the step reads the same box, so the records agree, and a system
+    // that drifts away from where it was set keeps all 24 bits for its own extent.
     double inv_len, inv_mass, theta, cth;
     int bucket;  // leaves are point masses judged like cells (the GPU program's tree)
 };
@@ -806,7 +808,8 @@ __device__ __forceinline__ void cell_record(const ComArgs &a, double cx, double 
 {
     width = ldexp(width0, -lvl);
     const double wt = width * a.inv_len / a.theta;  // width / dist < theta  <=>  dist > width / theta
-    rec = make_float4((float)((cx - a.ox) * a.inv_len), (float)((cy - a.oy) * a.inv_len), (float)(mtot * a.inv_mass),
+    const double ox = 0.5 * (a.box[0] + a.box[2]), oy = 0.5 * (a.box[1] + a.box[3]);
+    rec = make_float4((float)((cx - ox) * a.inv_len), (float)((cy - oy) * a.inv_len), (float)(mtot * a.inv_mass),
                       (float)(wt * wt));
     // Prune threshold: the cell's centre of mass lies inside the cell, so every point of
     // the cell is within dist(com) + diagonal of a target.  If that is below collision_th
@@ -829,7 +832,8 @@ __device__ __forceinline__ void multi_body_record(const ComArgs &a, double sx, d
         cell_record(a, cx, cy, mtot, (int)closed_level, width0, rec, width, prune);
     } else {
         // bodies at one position (equal in all 31 levels): they act as one body
-        rec = make_float4((float)((cx - a.ox) * a.inv_len), (float)((cy - a.oy) * a.inv_len), (float)(mtot * a.inv_mass),
+        const double ox = 0.5 * (a.box[0] + a.box[2]), oy = 0.5 * (a.box[1] + a.box[3]);
+        rec = make_float4((float)((cx - ox) * a.inv_len), (float)((cy - oy) * a.inv_len), (float)(mtot * a.inv_mass),
                           -(float)((rmax + a.cth) * a.inv_len));
         width = -rmax;
     }
@@ -860,9 +864,10 @@ __device__ __forceinline__ void store_node(const ComArgs &a, uint32_t u, const u
 // The same pass writes every body's float record {x, y, m, radius} in sorted order (the
 // traversal's targets and the one-body leaves), since it reads exactly what that needs.
 __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const uint32_t *idx, int n, const double2 *pos,
-                                                   const double *mass, const double *radius, double ox, double oy,
+                                                   const double *mass, const double *radius, const double *box,
                                                    double inv_len, double inv_mass, float4 *posm_s, double *leaf_sum)
 {
+    const double ox = 0.5 * (box[0] + box[2]), oy = 0.5 * (box[1] + box[3]);  // this step's origin
     const int lane = lane_id();
     const int chunk = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     if (chunk >= n)
@@ -1037,8 +1042,6 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.node_com = b.node_com;
     c.node_rec = b.node_rec;
     c.node_aux = b.node_child;
-    c.ox = a.units.origin[0];
-    c.oy = a.units.origin[1];
     c.inv_len = 1.0 / a.units.len_unit;
     c.inv_mass = 1.0 / a.units.mass_unit;
     c.theta = a.theta;
@@ -1047,7 +1050,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.cth = a.collision_th;
     c.bucket = a.bucket_depth > 0 ? 1 : 0;
     hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[b.sorted], b.idx[b.sorted], a.n, a.pos,
-                       a.mass, a.radius, c.ox, c.oy, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum);
+                       a.mass, a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum);
     // levels beyond the ones the build launched per-level kernels for: one block, one launch
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);

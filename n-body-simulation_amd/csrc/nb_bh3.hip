@@ -212,7 +212,7 @@ struct Com3Args {
     uint4 *node_aux;
     const uint32_t *cut;
     const double *leaf_sum;
-    double org[3];  // origin of the float coordinates
+    // float coordinates are relative to the middle of this step's bounding box (see nb_bh.hip)
     double inv_len, inv_mass, theta, cth;
 };
 
@@ -236,8 +236,9 @@ __device__ __forceinline__ void store_node3(const Com3Args &a, uint32_t u, const
     o[0] = make_double2(c[0], c[1]);
     o[1] = make_double2(c[2], mtot);
     o[2] = make_double2(width, 0.0);
-    a.node_rec[u] = make_float4((float)((c[0] - a.org[0]) * a.inv_len), (float)((c[1] - a.org[1]) * a.inv_len),
-                                (float)((c[2] - a.org[2]) * a.inv_len), (float)(mtot * a.inv_mass));
+    const double ox = 0.5 * (a.box[0] + a.box[2]), oy = 0.5 * (a.box[1] + a.box[3]), oz = 0.5 * (a.box[4] + a.box[5]);
+    a.node_rec[u] = make_float4((float)((c[0] - ox) * a.inv_len), (float)((c[1] - oy) * a.inv_len),
+                                (float)((c[2] - oz) * a.inv_len), (float)(mtot * a.inv_mass));
     a.node_aux[u] = make_uint4(__float_as_uint(open2), (meta.z << 4) | (meta.w & 0xffu), __float_as_uint(prune), 0u);
 }
 
@@ -246,10 +247,11 @@ __device__ __forceinline__ void store_node3(const Com3Args &a, uint32_t u, const
 // every body's float record in sorted order.  One wave per 64 consecutive sorted bodies, as
 // k_leaf_sums in nb_bh.hip.
 __global__ __launch_bounds__(256) void k_leaf_sums3(const uint64_t *keys, const uint32_t *idx, int n, const double *pos,
-                                                    const double *mass, const double *radius, double ox, double oy, double oz,
+                                                    const double *mass, const double *radius, const double *box,
                                                     double inv_len, double inv_mass, float4 *posm_s, float *rad_s,
                                                     double *leaf_sum)
 {
+    const double ox = 0.5 * (box[0] + box[2]), oy = 0.5 * (box[1] + box[3]), oz = 0.5 * (box[4] + box[5]);
     const int lane = lane_id();
     const int chunk = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     if (chunk >= n)
@@ -427,14 +429,12 @@ int bh3_com(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     c.node_aux = b.node_aux;
     c.cut = b.cut;
     c.leaf_sum = b.leaf_sum;
-    for (int d = 0; d < 3; ++d)
-        c.org[d] = a.units.origin[d];
     c.inv_len = 1.0 / a.units.len_unit;
     c.inv_mass = 1.0 / a.units.mass_unit;
     c.theta = a.theta;
     c.cth = a.collision_th;
     hipLaunchKernelGGL(k_leaf_sums3, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[0], b.idx[0], a.n, a.pos, a.mass,
-                       a.radius, c.org[0], c.org[1], c.org[2], c.inv_len, c.inv_mass, b.posm_s, b.rad_s, b.leaf_sum);
+                       a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.rad_s, b.leaf_sum);
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com3, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
     for (int d = b.launched - 1; d >= 0; --d)

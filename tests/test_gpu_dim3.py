@@ -388,3 +388,30 @@ def test_coincident_and_static_bodies(nb, oracle, alg):
         assert np.array_equal(out["acc"][20], b["acc"][20])
         assert np.allclose(out["vel"][20], b["vel"][20] + 25000.0 * b["acc"][20], rtol=1e-15)
     assert np.all(np.isfinite(out["pos"]))
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_a_drifting_system_keeps_its_precision_in_the_tree_path(nb, oracle, dims):
+    """Barnes-Hut takes its float coordinates relative to the middle of each step's bounding box: a
+    system that moves 20 times its own size away from where it was set loses nothing.  (The direct
+    sum keeps the origin of the last nb_set_bodies / nb_refresh_order.)"""
+    n = 2500
+    bulk = np.array([4.0e6, -3.0e6, 2.0e6])  # m/s: 1e11 m per step of 25 000 s
+    if dims == 2:
+        b = oracle.scenario(0, n, 16)
+        b["vel"] += bulk[:2]
+        Sim, accel = nb.NBodySim, oracle.bh_accel
+    else:
+        b = oracle.scenario3(0, n, 16, thickness=5.0e10)
+        b["vel"] += bulk
+        Sim, accel = nb.NBodySim3, oracle.bh_accel3
+    b["is_dynamic"][-1] = 1  # the sun travels with the rest
+    with Sim(n, nb.BARNES_HUT) as s:
+        s.set_bodies(b)
+        s.update(100)
+        out = s.read_bodies()
+        acc = s.compute_accel()
+    assert np.abs(out["pos"]).max() > 8.0e12
+    at = out.copy()
+    ref = accel(at)
+    assert rel_err(acc, ref).max() <= BH_TOL, rel_err(acc, ref).max()
