@@ -1,6 +1,8 @@
 """Randomised parity sweep against the CPU oracle (not collected by pytest; run by hand on a GPU box):
 
-    python tests/fuzz_parity.py [cases] [seed]
+    python tests/fuzz_parity.py [cases] [seed] [big]
+
+("big": sizes 8 000 .. 50 000 instead of 2 .. 3001; the oracle's direct sum then takes seconds per case.)
 
 Every case draws a scenario, a size, an opening angle, a cutoff, a softening length, the number of
 dimensions and the algorithm, and compares the library's accelerations (and a few steps) with the
@@ -26,7 +28,7 @@ for case in range(cases):
     dims = int(rng.choice([2, 3]))
     alg = int(rng.choice([0, 1]))
     sim = int(rng.choice([0, 1, 2]))
-    n = int(rng.choice([2, 3, 17, 64, 65, 200, 777, 1500, 3001]))
+    n = int(rng.choice([8000, 20000, 50000] if "big" in sys.argv[3:] else [2, 3, 17, 64, 65, 200, 777, 1500, 3001]))
     if sim == 2 and n < 4:
         n = 4
     theta = float(rng.choice([0.0, 0.2, 0.5, 0.5, 0.9, 1.5]))
@@ -71,6 +73,8 @@ for case in range(cases):
         dims, alg, sim, len(b), theta, cth, eps, thick if dims == 3 else 0.0, np.array2string(shift, precision=2), seed)
     if err > worst.get(key, (0.0, ""))[0]:
         worst[key] = (err, desc)
+    if "big" in sys.argv[3:]:
+        print("case %d: acc %.2e dpos %.2e : %s" % (case, err, dpos, desc), flush=True)  # the oracle takes a while
     if not (err <= tol) or not (dpos <= 1e-6):
         bad += 1
         print("MISS acc %.3e dpos %.3e : %s" % (err, dpos, desc), flush=True)
