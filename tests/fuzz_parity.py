@@ -78,6 +78,8 @@ for case in range(cases):
     if not (err <= tol) or not (dpos <= 1e-6):
         bad += 1
         print("MISS acc %.3e dpos %.3e : %s" % (err, dpos, desc), flush=True)
+    if case % 100 == 99:
+        print("... %d cases, %d misses so far" % (case + 1, bad), flush=True)
 for key in sorted(worst):
     print("worst dims %d alg %d: %.3e  (%s)" % (key[0], key[1], worst[key][0], worst[key][1]))
 print("%d cases, %d misses" % (cases, bad))
