@@ -111,6 +111,9 @@ void choose_units(nb_sim *s, const nb_body *b, int n)
     const double c3 = (double)s->fc.cth * s->fc.cth * s->fc.cth;
     s->fc.exact_denom = !((double)s->fc.eps3 <= std::ldexp(c3, -26));
     s->fc.eps2_negligible = (double)s->fc.eps2 <= std::ldexp((double)s->fc.cth * s->fc.cth, -26);
+    // coordinates lie in [-8, 8): their float rounding is up to 2.4e-7 units, i.e. a relative 5e-6 of a
+    // distance of 0.05 units (the reference's cutoff in its own scenarios is 0.145 units)
+    s->fc.precise_near = s->fc.cth < 0.05f;
 }
 
 // Exchange order = bodies sorted by a 2 x 16-bit Morton code of their initial positions.
@@ -218,9 +221,9 @@ int step_finish(nb_sim *s)
     if (s->alg == NB_ALG_DIRECT) {
         // records of the bodies other ranks advanced come from the gathered positions
         if (s->world > 1) {
-            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, 0, s->t0, s->units, s->p.collision_th,
+            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, s->n, 0, s->t0, s->units, s->p.collision_th,
                              s->posm[s->cur ^ 1], s->rad_s));
-            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, s->t1, s->n, s->units, s->p.collision_th,
+            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, s->n, s->t1, s->n, s->units, s->p.collision_th,
                              s->posm[s->cur ^ 1], s->rad_s));
         }
         s->cur ^= 1;
@@ -312,8 +315,11 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
     chk(dev_alloc(s->dyn, s->cap));
     if (alg == NB_ALG_DIRECT) {
         chk(dev_alloc(s->pos2, s->cap));
-        chk(dev_alloc(s->posm[0], direct_record_capacity(n)));
-        chk(dev_alloc(s->posm[1], direct_record_capacity(n)));
+        for (int k = 0; k < 2; ++k) {
+            chk(dev_alloc(s->posm[k], direct_record_floats4(n)));
+            if (rc == NB_OK && hipMemset(s->posm[k], 0, sizeof(float4) * direct_record_floats4(n)) != hipSuccess)
+                chk(fail(NB_ERR_HIP, "hipMemset failed"));
+        }
         chk(dev_alloc(s->rad_s, s->cap));
         s->jsplit = direct_choose_jsplit(n, n);
         chk(dev_alloc(s->part, (size_t)s->jsplit * n));
@@ -380,10 +386,10 @@ static int load_bodies(nb_sim *s, const nb_body *b, int n)
     NB_HIP(hipMemcpy(s->dyn, dyn.data(), n, hipMemcpyHostToDevice));
     if (s->alg == NB_ALG_DIRECT) {
         s->cur = 0;
-        NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, 0, n, s->units, s->p.collision_th, s->posm[0], s->rad_s));
+        NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, n, 0, n, s->units, s->p.collision_th, s->posm[0], s->rad_s));
         NB_TRY(pad_posm(s->stream, s->posm[0], n));
         // mass and cutoff radius never change: give the second buffer the same records
-        NB_HIP(hipMemcpyAsync(s->posm[1], s->posm[0], sizeof(float4) * direct_record_capacity(n),
+        NB_HIP(hipMemcpyAsync(s->posm[1], s->posm[0], sizeof(float4) * direct_record_floats4(n),
                               hipMemcpyDeviceToDevice, s->stream));
     }
     NB_HIP(hipStreamSynchronize(s->stream));

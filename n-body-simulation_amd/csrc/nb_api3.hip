@@ -81,6 +81,9 @@ void choose_units(nb_sim3 *s, const nb_body3 *b, int n)
     const double c3 = (double)s->fc.cth * s->fc.cth * s->fc.cth;
     s->fc.exact_denom = !((double)s->fc.eps3 <= std::ldexp(c3, -26));
     s->fc.eps2_negligible = (double)s->fc.eps2 <= std::ldexp((double)s->fc.cth * s->fc.cth, -26);
+    // coordinates lie in [-8, 8): their float rounding is up to 2.4e-7 units, i.e. a relative 5e-6 of a
+    // distance of 0.05 units (the reference's cutoff in its own scenarios is 0.145 units)
+    s->fc.precise_near = s->fc.cth < 0.05f;
 }
 
 // Bodies sorted by a 3 x 10-bit Morton code of their positions: index ranges are compact patches
@@ -187,8 +190,8 @@ int step_finish(nb_sim3 *s)
     s->first_kick = false;
     if (s->alg == NB_ALG_DIRECT) {
         if (s->world > 1) {
-            NB_TRY(pack_posm3_range(s->stream, s->pos2, s->mass, 0, s->t0, s->units, s->ds.posm[s->ds.cur ^ 1]));
-            NB_TRY(pack_posm3_range(s->stream, s->pos2, s->mass, s->t1, s->n, s->units, s->ds.posm[s->ds.cur ^ 1]));
+            NB_TRY(pack_posm3_range(s->stream, s->pos2, s->mass, s->n, 0, s->t0, s->units, s->ds.posm[s->ds.cur ^ 1]));
+            NB_TRY(pack_posm3_range(s->stream, s->pos2, s->mass, s->n, s->t1, s->n, s->units, s->ds.posm[s->ds.cur ^ 1]));
         }
         s->ds.cur ^= 1;
         std::swap(s->pos, s->pos2);
@@ -252,7 +255,7 @@ int load_bodies(nb_sim3 *s, const nb_body3 *b, int n)
         NB_TRY(pack_posm3(s->stream, s->pos, s->mass, s->radius, n, s->units, s->p.collision_th, s->ds.posm[0], s->ds.wcut,
                           s->ds.rad));
         // masses and padding never change: the other buffer starts as a copy
-        NB_HIP(hipMemcpyAsync(s->ds.posm[1], s->ds.posm[0], sizeof(float4) * direct3_record_capacity(n),
+        NB_HIP(hipMemcpyAsync(s->ds.posm[1], s->ds.posm[0], sizeof(float4) * 2 * direct3_record_capacity(n),
                               hipMemcpyDeviceToDevice, s->stream));
     }
     NB_HIP(hipStreamSynchronize(s->stream));
@@ -339,8 +342,8 @@ int nb3_create(const nb_params *params, int n, int alg, nb_sim3 **out)
     chk(dev_alloc(s->dyn, cap));
     if (alg == NB_ALG_DIRECT) {
         chk(dev_alloc(s->pos2, 3 * cap));
-        chk(dev_alloc(s->ds.posm[0], direct3_record_capacity(n)));
-        chk(dev_alloc(s->ds.posm[1], direct3_record_capacity(n)));
+        chk(dev_alloc(s->ds.posm[0], 2 * direct3_record_capacity(n)));
+        chk(dev_alloc(s->ds.posm[1], 2 * direct3_record_capacity(n)));
         chk(dev_alloc(s->ds.wcut, direct3_record_capacity(n)));
         chk(dev_alloc(s->ds.rad, cap));
         s->ds.jsplit = direct3_choose_jsplit(n, n);

@@ -62,6 +62,10 @@ struct ForceConsts {
     float cth;       // collision_th / len_unit
     int exact_denom; // 0: eps3 cannot change r^3 + eps3 in float for any pair outside the cutoff
     int eps2_negligible;  // 1: eps2 cannot change d^2 + eps2 in float for any pair outside the cutoff
+    int precise_near;     // 1: the cutoff is so small against the system's extent that the float rounding of
+                          // the coordinates (2^-24 of the extent) shows in the distance of the closest pairs
+                          // that still contribute: the direct sum then adds the coordinates' low parts for
+                          // runs near the cutoff (about a quarter more arithmetic there)
 };
 
 struct IntegrateArgs {
@@ -91,8 +95,14 @@ int pad_posm(hipStream_t s, float4 *posm, int n);
 size_t direct_meta_bytes(int n);
 
 // pos/mass/radius (double) -> posm records + scaled radius, bodies [i0, i1)
-int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int i0, int i1,
+// n: bodies in all (the low parts of the coordinates live behind the records, see direct_lo).
+int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int n, int i0, int i1,
               const Units &units, double collision_th, float4 *posm, float *rad);
+// A record array holds direct_record_floats4(n) float4: direct_record_capacity(n) records and,
+// behind them, as many float2 {x, y} "low parts": what rounding the scaled FP64 coordinate to the
+// record's float left over.  Runs near the cutoff add them so that the difference of two close
+// bodies carries float precision of the difference, not of the coordinates.
+size_t direct_record_floats4(int n);
 
 // ---- diagnostics (nb_diag.hip) ----
 // potential energy of the pairs outside the cutoff, FP64, O(n^2); *out is a device double

@@ -17,7 +17,10 @@ namespace nb {
 
 // ---- direct sum (nb_direct3.hip) ----
 struct Direct3State {
-    float4 *posm[2] = {nullptr, nullptr};  // {x, y, z, m} per body, internal units; [cur] is current
+    float4 *posm[2] = {nullptr, nullptr};  // {x, y, z, m} per body, internal units; [cur] is current; each holds
+                                           // 2 * direct3_record_capacity(n) float4: behind the records, the
+                                           // low parts {x, y, z, -} of the coordinates (what rounding the scaled
+                                           // FP64 coordinate to the record's float left over)
     int cur = 0;
     float *wcut = nullptr;  // radius + collision_th
     float *rad = nullptr;   // radius
@@ -38,7 +41,8 @@ int direct3_choose_jsplit(int n, int nt);
 int pack_posm3(hipStream_t s, const double *pos, const double *mass, const double *radius, int n, const Units &units,
                double collision_th, float4 *posm, float *wcut, float *rad);
 // Records of bodies [i0, i1) only (the ones other ranks advanced, from the gathered positions).
-int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int i0, int i1, const Units &units, float4 *posm);
+int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int n, int i0, int i1, const Units &units,
+                     float4 *posm);
 // One step for targets [t0, t0 + nt): reads posm[cur] and pos_cur, writes the targets' vel, acc,
 // pos_next and posm[cur ^ 1].
 int direct3_step(hipStream_t s, const Direct3State &st, int n, int t0, int nt, const ForceConsts &fc, const IntegrateArgs &ia,

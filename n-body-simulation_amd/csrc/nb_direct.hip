@@ -68,6 +68,8 @@ struct SubMeta {
 struct DirectLaunch {
     const float4 *posm_cur;
     float4 *posm_next;
+    const float2 *posl_cur;  // low parts of the coordinates of posm_cur
+    float2 *posl_next;
     const float *rad;
     const uint8_t *dyn;
     const double2 *pos_cur;  // FP64 positions the step starts from (never written by the step)
@@ -152,9 +154,11 @@ __device__ __forceinline__ void integrate_one(const DirectLaunch &a, int i, doub
         p.y += v.y * a.ia.dt;
         a.vel[i] = v;
         a.pos_next[i] = p;
-        rec.x = (float)((p.x - a.ia.origin[0]) * a.ia.inv_len_unit);
-        rec.y = (float)((p.y - a.ia.origin[1]) * a.ia.inv_len_unit);
+        const double qx = (p.x - a.ia.origin[0]) * a.ia.inv_len_unit, qy = (p.y - a.ia.origin[1]) * a.ia.inv_len_unit;
+        rec.x = (float)qx;
+        rec.y = (float)qy;
         a.posm_next[i] = rec;
+        a.posl_next[i] = make_float2((float)(qx - (double)rec.x), (float)(qy - (double)rec.y));
     }
 }
 
@@ -162,9 +166,10 @@ __device__ __forceinline__ void integrate_one(const DirectLaunch &a, int i, doub
 // cutoff comparison was too close to call: those are decided in FP64 on the FP64 positions, as
 // the reference does (Vector::getDistance, vector.cpp:31-35; isCollide, directSum.cpp:69-72).
 // Rare (a few pairs per million), so it runs as a separate loop after the hot one.
-template <bool EXACT>
-__device__ __forceinline__ double2 redo_ambiguous(const DirectLaunch &a, const float4 *rec, int jglobal, int jend,
-                                                  float xi, float yi, float ri, int ti)
+// (PRECISE as in run_pairs: the same distance must select the pairs here that the hot loop left out.)
+template <bool EXACT, bool PRECISE>
+__device__ __forceinline__ double2 redo_ambiguous(const DirectLaunch &a, const float4 *rec, const float2 *lo, int jglobal,
+                                                  int jend, float xi, float yi, float xl, float yl, float ri, int ti)
 {
     double ox = 0.0, oy = 0.0;
     const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
@@ -173,7 +178,12 @@ __device__ __forceinline__ double2 redo_ambiguous(const DirectLaunch &a, const f
 #pragma unroll 1
     for (int jj = 0; jj < DS_SUB; ++jj) {
         const float4 b = rec[jj];
-        const float dx = b.x - xi, dy = b.y - yi;
+        float dx = b.x - xi, dy = b.y - yi;
+        if (PRECISE) {
+            const float2 l = lo[jj];
+            dx += l.x - xl;
+            dy += l.y - yl;
+        }
         float r2 = __builtin_fmaf(dx, dx, eps2);
         r2 = __builtin_fmaf(dy, dy, r2);
         const float th = ri + b.w;
@@ -201,10 +211,15 @@ __device__ __forceinline__ double2 redo_ambiguous(const DirectLaunch &a, const f
 
 // All pairs of this thread's TPT targets with one run of DS_SUB staged records.
 // CUTOFF: apply the skip test; UNIFORM: every record has mass mu.
-template <int TPT, bool EXACT, bool CUTOFF, bool UNIFORM>
-__device__ __forceinline__ void run_pairs(const DirectLaunch &a, const float4 *rec, int jglobal, int jend, float mu,
-                                          const float (&xi)[TPT], const float (&yi)[TPT], const float (&ri)[TPT],
-                                          const int (&ti)[TPT], double (&sx)[TPT], double (&sy)[TPT])
+// A run that may hold pairs near the cutoff (CUTOFF) takes its coordinates as float pairs hi + lo
+// (lo, xl, yl: what rounding the FP64 coordinate to the float record left over), so that the
+// difference of two close bodies is exact to float precision of the DIFFERENCE, not of the
+// coordinates: the pairs that weigh most are the closest ones.
+template <int TPT, bool EXACT, bool CUTOFF, bool UNIFORM, bool PRECISE = false>
+__device__ __forceinline__ void run_pairs(const DirectLaunch &a, const float4 *rec, const float2 *lo, int jglobal, int jend,
+                                          float mu, const float (&xi)[TPT], const float (&yi)[TPT], const float (&xl)[TPT],
+                                          const float (&yl)[TPT], const float (&ri)[TPT], const int (&ti)[TPT],
+                                          double (&sx)[TPT], double (&sy)[TPT])
 {
     const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
     bool any_amb[TPT];
@@ -217,13 +232,25 @@ __device__ __forceinline__ void run_pairs(const DirectLaunch &a, const float4 *r
 #pragma unroll
         for (int k = 0; k < TPT; ++k)
             fx[k] = fy[k] = 0.f;
+        // the chunk's low parts: one coalesced load (lane L holds record c + L), handed out lane by lane
+        static_assert(DS_FLUSH <= 64, "one lane per record of a chunk");
+        float2 lchunk = make_float2(0.f, 0.f);
+        if (CUTOFF && PRECISE)
+            lchunk = lo[c + ((int)threadIdx.x & 63 & (DS_FLUSH - 1))];
 #pragma unroll NB_DS_UNROLL
         for (int jj = 0; jj < DS_FLUSH; ++jj) {
             const float4 b = rec[c + jj];
+            float2 l = make_float2(0.f, 0.f);
+            if (CUTOFF && PRECISE)
+                l = make_float2(__shfl(lchunk.x, jj), __shfl(lchunk.y, jj));
 #pragma unroll
             for (int k = 0; k < TPT; ++k) {
-                const float dx = b.x - xi[k];
-                const float dy = b.y - yi[k];
+                float dx = b.x - xi[k];
+                float dy = b.y - yi[k];
+                if (CUTOFF && PRECISE) {
+                    dx += l.x - xl[k];
+                    dy += l.y - yl[k];
+                }
                 float r2 = __builtin_fmaf(dx, dx, eps2);
                 r2 = __builtin_fmaf(dy, dy, r2);
                 float s;
@@ -259,7 +286,7 @@ __device__ __forceinline__ void run_pairs(const DirectLaunch &a, const float4 *r
 #pragma unroll
         for (int k = 0; k < TPT; ++k)
             if (any_amb[k]) {
-                const double2 extra = redo_ambiguous<EXACT>(a, rec, jglobal, jend, xi[k], yi[k], ri[k], ti[k]);
+                const double2 extra = redo_ambiguous<EXACT, PRECISE>(a, rec, lo, jglobal, jend, xi[k], yi[k], xl[k], yl[k], ri[k], ti[k]);
                 sx[k] += extra.x;
                 sy[k] += extra.y;
             }
@@ -347,7 +374,7 @@ __device__ __forceinline__ void stage_tile(const float4 *src, float4 *dst, int t
 #endif
 }
 
-template <int TPT, bool EXACT>
+template <int TPT, bool EXACT, bool PRECISE>
 __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
 {
     __shared__ __attribute__((aligned(16))) float4 tile[2][DS_TILE];
@@ -363,7 +390,7 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
     const int ntile = (jend - jbeg + DS_TILE - 1) / DS_TILE;
     stage_tile(a.posm_cur + jbeg, tile[0], tid);
 
-    float xi[TPT], yi[TPT], ri[TPT];
+    float xi[TPT], yi[TPT], xl[TPT], yl[TPT], ri[TPT];
     int ti[TPT];
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
@@ -371,8 +398,11 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
         // threads past the end work on a copy of the last target and discard the result
         ti[k] = i < tend ? i : tend - 1;
         const float4 self = a.posm_cur[ti[k]];
+        const float2 selfl = a.posl_cur[ti[k]];
         xi[k] = self.x;
         yi[k] = self.y;
+        xl[k] = selfl.x;
+        yl[k] = selfl.y;
         ri[k] = a.rad[ti[k]];
     }
     double sx[TPT], sy[TPT];
@@ -438,11 +468,12 @@ __global__ __launch_bounds__(DS_BLOCK) void k_direct(DirectLaunch a)
                     else
                         run_pairs_far<TPT, false>(a, rec, 0.f, xi, yi, sx, sy);
                 } else if (uni)
-                    run_pairs<TPT, EXACT, false, true>(a, rec, j0, jend, m.mu, xi, yi, ri, ti, sx, sy);
+                    run_pairs<TPT, EXACT, false, true>(a, rec, nullptr, j0, jend, m.mu, xi, yi, xl, yl, ri, ti, sx, sy);
                 else
-                    run_pairs<TPT, EXACT, false, false>(a, rec, j0, jend, 0.f, xi, yi, ri, ti, sx, sy);
+                    run_pairs<TPT, EXACT, false, false>(a, rec, nullptr, j0, jend, 0.f, xi, yi, xl, yl, ri, ti, sx, sy);
             } else {
-                run_pairs<TPT, EXACT, true, false>(a, rec, j0, jend, 0.f, xi, yi, ri, ti, sx, sy);
+                // the low parts come straight from memory: every lane reads the same address
+                run_pairs<TPT, EXACT, true, false, PRECISE>(a, rec, a.posl_cur + j0, j0, jend, 0.f, xi, yi, xl, yl, ri, ti, sx, sy);
             }
         }
         // the next tile has landed (the barrier waits for this wave's outstanding copies), and
@@ -479,14 +510,16 @@ __global__ __launch_bounds__(256) void k_direct_finish(DirectLaunch a)
 
 __global__ __launch_bounds__(256) void k_pack_posm(const double2 *pos, const double *mass, const double *radius, int i0,
                                                    int i1, double ox, double oy, double inv_len, double inv_mass,
-                                                   double cth, float4 *posm, float *rad)
+                                                   double cth, float4 *posm, float2 *posl, float *rad)
 {
     const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= i1)
         return;
     const double2 p = pos[i];
-    posm[i] = make_float4((float)((p.x - ox) * inv_len), (float)((p.y - oy) * inv_len), (float)(mass[i] * inv_mass),
-                          (float)((radius[i] + cth) * inv_len));
+    const double qx = (p.x - ox) * inv_len, qy = (p.y - oy) * inv_len;
+    const float hx = (float)qx, hy = (float)qy;
+    posm[i] = make_float4(hx, hy, (float)(mass[i] * inv_mass), (float)((radius[i] + cth) * inv_len));
+    posl[i] = make_float2((float)(qx - (double)hx), (float)(qy - (double)hy));
     rad[i] = (float)(radius[i] * inv_len);
 }
 
@@ -500,6 +533,9 @@ __global__ __launch_bounds__(256) void k_pad_posm(float4 *posm, int n, int cap)
 }
 
 size_t direct_record_capacity(int n) { return ((size_t)n + DS_TILE - 1) / DS_TILE * DS_TILE + DS_TILE; }
+size_t direct_record_floats4(int n) { return direct_record_capacity(n) + direct_record_capacity(n) / 2; }
+
+static float2 *direct_lo(const float4 *posm, int n) { return (float2 *)(posm + direct_record_capacity(n)); }
 
 int pad_posm(hipStream_t s, float4 *posm, int n)
 {
@@ -509,14 +545,14 @@ int pad_posm(hipStream_t s, float4 *posm, int n)
     return NB_OK;
 }
 
-int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int i0, int i1,
+int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int n, int i0, int i1,
               const Units &units, double collision_th, float4 *posm, float *rad)
 {
     if (i1 <= i0)
         return NB_OK;
     const int blocks = (i1 - i0 + 255) / 256;
     hipLaunchKernelGGL(k_pack_posm, dim3(blocks), dim3(256), 0, s, pos, mass, radius, i0, i1, units.origin[0],
-                       units.origin[1], 1.0 / units.len_unit, 1.0 / units.mass_unit, collision_th, posm, rad);
+                       units.origin[1], 1.0 / units.len_unit, 1.0 / units.mass_unit, collision_th, posm, direct_lo(posm, n), rad);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -560,6 +596,8 @@ int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const 
     DirectLaunch a;
     a.posm_cur = posm_cur;
     a.posm_next = posm_next;
+    a.posl_cur = direct_lo(posm_cur, n);
+    a.posl_next = direct_lo(posm_next, n);
     a.rad = rad;
     a.dyn = dyn;
     a.pos_cur = pos_cur;
@@ -583,10 +621,14 @@ int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const 
     const int nsub = (n + DS_SUB - 1) / DS_SUB;
     hipLaunchKernelGGL(k_sub_meta, dim3((nsub + 3) / 4), dim3(256), 0, s, posm_cur, n, (SubMeta *)meta);
     dim3 grid((nt + DS_BLOCK * DS_TPT - 1) / (DS_BLOCK * DS_TPT), a.jsplit);
-    if (fc.exact_denom)
-        hipLaunchKernelGGL((k_direct<DS_TPT, true>), grid, dim3(DS_BLOCK), 0, s, a);
+    if (fc.exact_denom && fc.precise_near)
+        hipLaunchKernelGGL((k_direct<DS_TPT, true, true>), grid, dim3(DS_BLOCK), 0, s, a);
+    else if (fc.exact_denom)
+        hipLaunchKernelGGL((k_direct<DS_TPT, true, false>), grid, dim3(DS_BLOCK), 0, s, a);
+    else if (fc.precise_near)
+        hipLaunchKernelGGL((k_direct<DS_TPT, false, true>), grid, dim3(DS_BLOCK), 0, s, a);
     else
-        hipLaunchKernelGGL((k_direct<DS_TPT, false>), grid, dim3(DS_BLOCK), 0, s, a);
+        hipLaunchKernelGGL((k_direct<DS_TPT, false, false>), grid, dim3(DS_BLOCK), 0, s, a);
     NB_HIP(hipGetLastError());
     if (a.jsplit > 1) {
         hipLaunchKernelGGL(k_direct_finish, dim3((nt + 255) / 256), dim3(256), 0, s, a);

@@ -37,6 +37,8 @@ struct SubMeta3 {
 struct Direct3Launch {
     const float4 *posm_cur;
     float4 *posm_next;
+    const float4 *posl_cur;  // low parts of the coordinates of posm_cur
+    float4 *posl_next;
     const float *wcut;  // radius + collision_th per body
     const float *rad;   // radius per body
     const uint8_t *dyn;
@@ -105,15 +107,18 @@ __device__ __forceinline__ void integrate_one3(const Direct3Launch &a, int i, co
     for (int k = 0; k < 3; ++k)
         a.acc[3 * (size_t)i + k] = acc[k];
     if (a.ia.do_integrate) {
-        float q[3];
+        float q[3], l[3];
         for (int k = 0; k < 3; ++k) {
             const double v = a.vel[3 * (size_t)i + k] + acc[k] * a.ia.dt_kick;
             const double p = a.pos_cur[3 * (size_t)i + k] + v * a.ia.dt;
             a.vel[3 * (size_t)i + k] = v;
             a.pos_next[3 * (size_t)i + k] = p;
-            q[k] = (float)((p - a.ia.origin[k]) * a.ia.inv_len_unit);
+            const double s64 = (p - a.ia.origin[k]) * a.ia.inv_len_unit;
+            q[k] = (float)s64;
+            l[k] = (float)(s64 - (double)q[k]);
         }
         a.posm_next[i] = make_float4(q[0], q[1], q[2], rec.w);
+        a.posl_next[i] = make_float4(l[0], l[1], l[2], 0.f);
     }
 }
 
@@ -127,9 +132,11 @@ __device__ __forceinline__ float pair_scale(bool exact, float r2, float eps3)
 
 // The pairs of one target with one run whose float cutoff comparison was too close to call,
 // decided in FP64 on the FP64 positions (isCollide, directSum.cpp:69-72: >=).
-template <bool EXACT>
-__device__ __forceinline__ void redo_ambiguous3(const Direct3Launch &a, const float4 *rec, const float *wc, int jglobal,
-                                                int jend, float xi, float yi, float zi, float ri, int ti, double (&s)[3])
+// (PRECISE as in run_pairs3: the same distance must select the pairs here that the hot loop left out.)
+template <bool EXACT, bool PRECISE>
+__device__ __forceinline__ void redo_ambiguous3(const Direct3Launch &a, const float4 *rec, const float *wc, const float4 *lo,
+                                                int jglobal, int jend, float xi, float yi, float zi, const float (&tl)[3],
+                                                float ri, int ti, double (&s)[3])
 {
     const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
     const double *pi = a.pos_cur + 3 * (size_t)ti;
@@ -137,7 +144,13 @@ __device__ __forceinline__ void redo_ambiguous3(const Direct3Launch &a, const fl
 #pragma unroll 1
     for (int jj = 0; jj < DS3_SUB; ++jj) {
         const float4 b = rec[jj];
-        const float dx = b.x - xi, dy = b.y - yi, dz = b.z - zi;
+        float dx = b.x - xi, dy = b.y - yi, dz = b.z - zi;
+        if (PRECISE) {
+            const float4 l = lo[jj];
+            dx += l.x - tl[0];
+            dy += l.y - tl[1];
+            dz += l.z - tl[2];
+        }
         float r2 = __builtin_fmaf(dx, dx, eps2);
         r2 = __builtin_fmaf(dy, dy, r2);
         r2 = __builtin_fmaf(dz, dz, r2);
@@ -158,11 +171,15 @@ __device__ __forceinline__ void redo_ambiguous3(const Direct3Launch &a, const fl
     }
 }
 
-// All pairs of this thread's TPT targets with one run of DS3_SUB staged records.
-template <int TPT, bool EXACT, bool CUTOFF, bool UNIFORM>
-__device__ __forceinline__ void run_pairs3(const Direct3Launch &a, const float4 *rec, const float *wc, int jglobal, int jend,
-                                           float mu, const float (&xi)[TPT], const float (&yi)[TPT], const float (&zi)[TPT],
-                                           const float (&ri)[TPT], const int (&ti)[TPT], double (&acc)[TPT][3])
+// All pairs of this thread's TPT targets with one run of DS3_SUB staged records.  A run that may
+// hold pairs near the cutoff (CUTOFF) takes its coordinates as float pairs hi + lo (lo, tl: what
+// rounding the FP64 coordinate to the float record left over), so that the difference of two close
+// bodies is exact to float precision of the difference, not of the coordinates.
+template <int TPT, bool EXACT, bool CUTOFF, bool UNIFORM, bool PRECISE = false>
+__device__ __forceinline__ void run_pairs3(const Direct3Launch &a, const float4 *rec, const float *wc, const float4 *lo,
+                                           int jglobal, int jend, float mu, const float (&xi)[TPT], const float (&yi)[TPT],
+                                           const float (&zi)[TPT], const float (&tl)[TPT][3], const float (&ri)[TPT],
+                                           const int (&ti)[TPT], double (&acc)[TPT][3])
 {
     const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
     bool any_amb[TPT];
@@ -175,13 +192,26 @@ __device__ __forceinline__ void run_pairs3(const Direct3Launch &a, const float4 
 #pragma unroll
         for (int k = 0; k < TPT; ++k)
             fx[k] = fy[k] = fz[k] = 0.f;
+        // the chunk's low parts: one coalesced load (lane L holds record c + L), handed out lane by lane
+        static_assert(DS3_FLUSH <= 64, "one lane per record of a chunk");
+        float4 lchunk = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CUTOFF && PRECISE)
+            lchunk = lo[c + ((int)threadIdx.x & 63 & (DS3_FLUSH - 1))];
 #pragma unroll 8
         for (int jj = 0; jj < DS3_FLUSH; ++jj) {
             const float4 b = rec[c + jj];
             const float wj = CUTOFF ? wc[c + jj] : 0.f;
+            float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (CUTOFF && PRECISE)
+                l = make_float4(__shfl(lchunk.x, jj), __shfl(lchunk.y, jj), __shfl(lchunk.z, jj), 0.f);
 #pragma unroll
             for (int k = 0; k < TPT; ++k) {
-                const float dx = b.x - xi[k], dy = b.y - yi[k], dz = b.z - zi[k];
+                float dx = b.x - xi[k], dy = b.y - yi[k], dz = b.z - zi[k];
+                if (CUTOFF && PRECISE) {
+                    dx += l.x - tl[k][0];
+                    dy += l.y - tl[k][1];
+                    dz += l.z - tl[k][2];
+                }
                 float r2 = __builtin_fmaf(dx, dx, eps2);
                 r2 = __builtin_fmaf(dy, dy, r2);
                 r2 = __builtin_fmaf(dz, dz, r2);
@@ -211,7 +241,7 @@ __device__ __forceinline__ void run_pairs3(const Direct3Launch &a, const float4 
 #pragma unroll
         for (int k = 0; k < TPT; ++k)
             if (any_amb[k])
-                redo_ambiguous3<EXACT>(a, rec, wc, jglobal, jend, xi[k], yi[k], zi[k], ri[k], ti[k], acc[k]);
+                redo_ambiguous3<EXACT, PRECISE>(a, rec, wc, lo, jglobal, jend, xi[k], yi[k], zi[k], tl[k], ri[k], ti[k], acc[k]);
     }
 }
 
@@ -288,7 +318,7 @@ __device__ __forceinline__ void stage_tile3(const float4 *src, const float *wsrc
     }
 }
 
-template <int TPT, bool EXACT>
+template <int TPT, bool EXACT, bool PRECISE>
 __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
 {
     __shared__ __attribute__((aligned(16))) float4 tile[2][DS3_TILE];
@@ -305,7 +335,7 @@ __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
     const int ntile = (jend - jbeg + DS3_TILE - 1) / DS3_TILE;
     stage_tile3(a.posm_cur + jbeg, a.wcut + jbeg, tile[0], wtile[0], tid);
 
-    float xi[TPT], yi[TPT], zi[TPT], ri[TPT];
+    float xi[TPT], yi[TPT], zi[TPT], tl[TPT][3], ri[TPT];
     int ti[TPT];
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
@@ -315,6 +345,10 @@ __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
         xi[k] = self.x;
         yi[k] = self.y;
         zi[k] = self.z;
+        const float4 selfl = a.posl_cur[ti[k]];
+        tl[k][0] = selfl.x;
+        tl[k][1] = selfl.y;
+        tl[k][2] = selfl.z;
         ri[k] = a.rad[ti[k]];
     }
     double acc[TPT][3];
@@ -387,11 +421,12 @@ __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
                 else
                     run_pairs3_far<TPT, false>(a, rec, 0.f, xi, yi, zi, acc);
             } else if (far && uni)
-                run_pairs3<TPT, EXACT, false, true>(a, rec, wc, j0, jend, m.mu, xi, yi, zi, ri, ti, acc);
+                run_pairs3<TPT, EXACT, false, true>(a, rec, wc, nullptr, j0, jend, m.mu, xi, yi, zi, tl, ri, ti, acc);
             else if (far)
-                run_pairs3<TPT, EXACT, false, false>(a, rec, wc, j0, jend, 0.f, xi, yi, zi, ri, ti, acc);
-            else
-                run_pairs3<TPT, EXACT, true, false>(a, rec, wc, j0, jend, 0.f, xi, yi, zi, ri, ti, acc);
+                run_pairs3<TPT, EXACT, false, false>(a, rec, wc, nullptr, j0, jend, 0.f, xi, yi, zi, tl, ri, ti, acc);
+            else  // the low parts come straight from memory: every lane reads the same address
+                run_pairs3<TPT, EXACT, true, false, PRECISE>(a, rec, wc, a.posl_cur + j0, j0, jend, 0.f, xi, yi, zi, tl, ri, ti,
+                                                             acc);
         }
         __syncthreads();  // the next tile has landed and every wave is done with the current one
     }
@@ -432,16 +467,21 @@ __global__ __launch_bounds__(256) void k_direct3_finish(Direct3Launch a)
 // far away, infinite cutoff), so whole tiles can be staged without a bounds test.
 __global__ __launch_bounds__(256) void k_pack_posm3(const double *pos, const double *mass, const double *radius, int i0, int i1,
                                                     int n, int cap, double ox, double oy, double oz, double inv_len,
-                                                    double inv_mass, double cth, float4 *posm, float *wcut, float *rad)
+                                                    double inv_mass, double cth, float4 *posm, float4 *posl, float *wcut,
+                                                    float *rad)
 {
     const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i < i1 && i < n) {
-        posm[i] = make_float4((float)((pos[3 * (size_t)i] - ox) * inv_len), (float)((pos[3 * (size_t)i + 1] - oy) * inv_len),
-                              (float)((pos[3 * (size_t)i + 2] - oz) * inv_len), (float)(mass[i] * inv_mass));
+        const double q[3] = {(pos[3 * (size_t)i] - ox) * inv_len, (pos[3 * (size_t)i + 1] - oy) * inv_len,
+                             (pos[3 * (size_t)i + 2] - oz) * inv_len};
+        const float h[3] = {(float)q[0], (float)q[1], (float)q[2]};
+        posm[i] = make_float4(h[0], h[1], h[2], (float)(mass[i] * inv_mass));
+        posl[i] = make_float4((float)(q[0] - (double)h[0]), (float)(q[1] - (double)h[1]), (float)(q[2] - (double)h[2]), 0.f);
         wcut[i] = (float)((radius[i] + cth) * inv_len);
         rad[i] = (float)(radius[i] * inv_len);
     } else if (i >= n && i < cap) {
         posm[i] = make_float4(1.0e15f, 1.0e15f, 1.0e15f, 0.f);
+        posl[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         wcut[i] = __builtin_inff();
     }
 }
@@ -455,7 +495,7 @@ int pack_posm3(hipStream_t s, const double *pos, const double *mass, const doubl
     const int cap = (int)direct3_record_capacity(n);
     hipLaunchKernelGGL(k_pack_posm3, dim3((cap + 255) / 256), dim3(256), 0, s, pos, mass, radius, 0, cap, n, cap,
                        units.origin[0], units.origin[1], units.origin[2], 1.0 / units.len_unit, 1.0 / units.mass_unit,
-                       collision_th, posm, wcut, rad);
+                       collision_th, posm, posm + cap, wcut, rad);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -476,20 +516,27 @@ int direct3_choose_jsplit(int n, int nt)
 }
 
 __global__ __launch_bounds__(256) void k_pack_posm3_range(const double *pos, const double *mass, int i0, int i1, double ox,
-                                                          double oy, double oz, double inv_len, double inv_mass, float4 *posm)
+                                                          double oy, double oz, double inv_len, double inv_mass, float4 *posm,
+                                                          float4 *posl)
 {
     const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < i1)
-        posm[i] = make_float4((float)((pos[3 * (size_t)i] - ox) * inv_len), (float)((pos[3 * (size_t)i + 1] - oy) * inv_len),
-                              (float)((pos[3 * (size_t)i + 2] - oz) * inv_len), (float)(mass[i] * inv_mass));
+    if (i < i1) {
+        const double q[3] = {(pos[3 * (size_t)i] - ox) * inv_len, (pos[3 * (size_t)i + 1] - oy) * inv_len,
+                             (pos[3 * (size_t)i + 2] - oz) * inv_len};
+        const float h[3] = {(float)q[0], (float)q[1], (float)q[2]};
+        posm[i] = make_float4(h[0], h[1], h[2], (float)(mass[i] * inv_mass));
+        posl[i] = make_float4((float)(q[0] - (double)h[0]), (float)(q[1] - (double)h[1]), (float)(q[2] - (double)h[2]), 0.f);
+    }
 }
 
-int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int i0, int i1, const Units &units, float4 *posm)
+int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int n, int i0, int i1, const Units &units,
+                     float4 *posm)
 {
     if (i1 <= i0)
         return NB_OK;
     hipLaunchKernelGGL(k_pack_posm3_range, dim3((i1 - i0 + 255) / 256), dim3(256), 0, s, pos, mass, i0, i1, units.origin[0],
-                       units.origin[1], units.origin[2], 1.0 / units.len_unit, 1.0 / units.mass_unit, posm);
+                       units.origin[1], units.origin[2], 1.0 / units.len_unit, 1.0 / units.mass_unit, posm,
+                       posm + direct3_record_capacity(n));
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -504,6 +551,8 @@ int direct3_step(hipStream_t s, const Direct3State &st, int n, int t0, int nt, c
     Direct3Launch a;
     a.posm_cur = st.posm[st.cur];
     a.posm_next = st.posm[st.cur ^ 1];
+    a.posl_cur = a.posm_cur + direct3_record_capacity(n);
+    a.posl_next = a.posm_next + direct3_record_capacity(n);
     a.wcut = st.wcut;
     a.rad = st.rad;
     a.dyn = st.dyn;
@@ -528,10 +577,14 @@ int direct3_step(hipStream_t s, const Direct3State &st, int n, int t0, int nt, c
     const int nsub = (n + DS3_SUB - 1) / DS3_SUB;
     hipLaunchKernelGGL(k_sub_meta3, dim3((nsub + 3) / 4), dim3(256), 0, s, a.posm_cur, a.wcut, n, (SubMeta3 *)st.meta);
     dim3 grid((nt + DS3_BLOCK * DS3_TPT - 1) / (DS3_BLOCK * DS3_TPT), a.jsplit);
-    if (fc.exact_denom)
-        hipLaunchKernelGGL((k_direct3<DS3_TPT, true>), grid, dim3(DS3_BLOCK), 0, s, a);
+    if (fc.exact_denom && fc.precise_near)
+        hipLaunchKernelGGL((k_direct3<DS3_TPT, true, true>), grid, dim3(DS3_BLOCK), 0, s, a);
+    else if (fc.exact_denom)
+        hipLaunchKernelGGL((k_direct3<DS3_TPT, true, false>), grid, dim3(DS3_BLOCK), 0, s, a);
+    else if (fc.precise_near)
+        hipLaunchKernelGGL((k_direct3<DS3_TPT, false, true>), grid, dim3(DS3_BLOCK), 0, s, a);
     else
-        hipLaunchKernelGGL((k_direct3<DS3_TPT, false>), grid, dim3(DS3_BLOCK), 0, s, a);
+        hipLaunchKernelGGL((k_direct3<DS3_TPT, false, false>), grid, dim3(DS3_BLOCK), 0, s, a);
     NB_HIP(hipGetLastError());
     if (a.jsplit > 1) {
         hipLaunchKernelGGL(k_direct3_finish, dim3((nt + 255) / 256), dim3(256), 0, s, a);
