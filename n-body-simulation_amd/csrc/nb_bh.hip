@@ -246,7 +246,6 @@ __global__ __launch_bounds__(256) void k_sort_count(const uint64_t *keys, int n,
 __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *data, int count)
 {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_sh;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int per = (count + 1023) / 1024;
     const int beg = tid * per;
@@ -275,7 +274,6 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *data, int count)
         data[i] = run;
         run += v;
     }
-    (void)carry_sh;
 }
 
 // Sort pass, step 2: one block per digit.  Exclusive scan of the digit's per-block counts in
