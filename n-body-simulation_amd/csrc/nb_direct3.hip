@@ -323,8 +323,9 @@ __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
 {
     __shared__ __attribute__((aligned(16))) float4 tile[2][DS3_TILE];
     __shared__ __attribute__((aligned(16))) float wtile[2][DS3_TILE];
-    __shared__ float red[4][7];
     const int tid = threadIdx.x;
+    // a wave's targets are consecutive bodies: lane l takes tbase + 64 TPT wave + l, + 64, ...
+    const int wbase = (tid >> 6) * (64 * TPT) + (tid & 63);
     const int tbase = a.t0 + blockIdx.x * (DS3_BLOCK * TPT);
     const int tend = a.t0 + a.nt;
 
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
     int ti[TPT];
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
-        const int i = tbase + tid + k * DS3_BLOCK;
+        const int i = tbase + wbase + k * 64;
         ti[k] = i < tend ? i : tend - 1;  // threads past the end repeat the last target and discard it
         const float4 self = a.posm_cur[ti[k]];
         xi[k] = self.x;
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
     for (int k = 0; k < TPT; ++k)
         acc[k][0] = acc[k][1] = acc[k][2] = 0.0;
 
-    // bounding box of the block's targets and their largest radius
+    // bounding box of the WAVE's targets (64 TPT consecutive bodies) and their largest radius:
+    // every wave decides by itself which runs are far (tighter boxes, fewer near runs)
     float lo[3] = {xi[0], yi[0], zi[0]}, hi[3] = {xi[0], yi[0], zi[0]}, rimax = ri[0];
 #pragma unroll
     for (int k = 1; k < TPT; ++k) {
@@ -377,21 +379,13 @@ __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
         }
         rimax = fmaxf(rimax, __shfl_xor(rimax, o));
     }
-    if ((tid & 63) == 0) {
-        float *r = red[tid >> 6];
-        for (int d = 0; d < 3; ++d) {
-            r[2 * d] = lo[d];
-            r[2 * d + 1] = hi[d];
-        }
-        r[6] = rimax;
-    }
-    __syncthreads();  // also completes the staging of tile 0
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        lo[d] = uniform_f3(fminf(fminf(red[0][2 * d], red[1][2 * d]), fminf(red[2][2 * d], red[3][2 * d])));
-        hi[d] = uniform_f3(fmaxf(fmaxf(red[0][2 * d + 1], red[1][2 * d + 1]), fmaxf(red[2][2 * d + 1], red[3][2 * d + 1])));
+        lo[d] = uniform_f3(lo[d]);
+        hi[d] = uniform_f3(hi[d]);
     }
-    rimax = uniform_f3(fmaxf(fmaxf(red[0][6], red[1][6]), fmaxf(red[2][6], red[3][6])));
+    rimax = uniform_f3(rimax);
+    __syncthreads();  // completes the staging of tile 0
 
     for (int t = 0; t < ntile; ++t) {
         if (t + 1 < ntile)
@@ -433,7 +427,7 @@ __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
 
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
-        const int i = tbase + tid + k * DS3_BLOCK;
+        const int i = tbase + wbase + k * 64;
         if (i >= tend)
             continue;
         if (a.jsplit == 1) {
