@@ -13,7 +13,7 @@ with nb.NBodySim(n, nb.BARNES_HUT) as sim:
     sim.set_bodies(b)
     sim.sync()
     out = []
-    for chunk in (3, 10, 10, 20, 40, 80, 160):
+    for chunk in (3, 5, 5, 5, 5, 5, 5, 5, 5, 10, 10):
         t = time.perf_counter()
         sim.update(chunk)
         sim.sync()
