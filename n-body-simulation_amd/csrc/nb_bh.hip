@@ -1010,7 +1010,8 @@ __device__ __forceinline__ void com_level(const ComArgs &a, int d)
 }
 
 // d_hi == d + 1: level d by the whole grid.  d_hi > d + 1: levels d_hi-1 down to d by ONE block
-// in one launch (the levels past the ones the host expects to exist, normally empty).
+// in one launch (the levels past the ones the host expects to exist, normally empty, and the
+// few hundred cells of the top levels).
 __global__ __launch_bounds__(256) void k_com(ComArgs a, int d, int d_hi)
 {
     if (d_hi > d + 1) {
@@ -1025,6 +1026,8 @@ __global__ __launch_bounds__(256) void k_com(ComArgs a, int d, int d_hi)
     }
     com_level(a, d);
 }
+
+constexpr int COM_TOP_LEVELS = 5;  // levels 0..4: at most 341 cells
 
 int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
@@ -1052,8 +1055,14 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     // levels beyond the ones the build launched per-level kernels for: one block, one launch
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
-    for (int d = b.launched - 1; d >= 0; --d)
+    // the top levels hold a few hundred nodes at most (4^d): one block does them in one launch
+    const int top = b.launched < COM_TOP_LEVELS ? b.launched : COM_TOP_LEVELS;
+    for (int d = b.launched - 1; d >= top; --d)
         hipLaunchKernelGGL(k_com, dim3(level_blocks(d, 2, 256)), dim3(256), 0, s, c, d, d + 1);
+    if (top == 1)
+        hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, 0, 1);
+    else if (top > 1)
+        hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, 0, top);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }

@@ -400,7 +400,8 @@ __device__ __forceinline__ void com3_level(const Com3Args &a, int d)
 __global__ __launch_bounds__(256) void k_com3(Com3Args a, int d, int d_hi)
 {
     if (d_hi > d + 1) {
-        // levels past the ones the host expects to exist (normally empty), by one block
+        // several levels by one block: those past the ones the host expects to exist (normally
+        // empty), and the few hundred cells of the top levels
         for (int dd = d_hi - 1; dd >= d; --dd) {
             if (a.level_start[dd + 1] > a.level_start[dd]) {  // uniform
                 com3_level(a, dd);
@@ -437,8 +438,15 @@ int bh3_com(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
                        a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.rad_s, b.leaf_sum);
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com3, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
-    for (int d = b.launched - 1; d >= 0; --d)
+    // the top levels hold a few hundred nodes at most (8^d): one block does them in one launch
+    constexpr int COM3_TOP_LEVELS = 4;  // levels 0..3: at most 585 cells
+    const int top = b.launched < COM3_TOP_LEVELS ? b.launched : COM3_TOP_LEVELS;
+    for (int d = b.launched - 1; d >= top; --d)
         hipLaunchKernelGGL(k_com3, dim3(level_blocks(d, 3, 256)), dim3(256), 0, s, c, d, d + 1);
+    if (top == 1)
+        hipLaunchKernelGGL(k_com3, dim3(1), dim3(256), 0, s, c, 0, 1);
+    else if (top > 1)
+        hipLaunchKernelGGL(k_com3, dim3(1), dim3(256), 0, s, c, 0, top);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
