@@ -1,6 +1,7 @@
 """One process per GPU: every rank holds all bodies, integrates its slice of the exchange
 order and all-gathers the new positions each step (RCCL over xGMI through
-torch.distributed's "nccl" backend; "gloo" on CPU tensors for the host-logic tests).
+torch.distributed's "nccl" backend; "gloo" for the host-logic tests on CPU and for ranks that
+share one GPU, the gathered slices then pass through host memory).
 
 The reference is single-GPU; this layer has no counterpart there.  The engine it drives
 only has to offer
@@ -88,8 +89,11 @@ class DistributedSim:
             # in place: every rank's slice already sits at its offset in the output
             dist.all_gather_into_tensor(buf, mine, group=self.group)
         else:
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
-            dist.all_gather(parts, mine.clone(), group=self.group)
+            # gloo gathers host tensors: a device slice is staged through the host (.cpu() waits for
+            # the kernels queued on torch's current stream, which is the engine's stream)
+            send = mine.cpu() if mine.is_cuda else mine.clone()
+            parts = [torch.empty_like(send) for _ in range(self.world)]
+            dist.all_gather(parts, send, group=self.group)
             for r, p in enumerate(parts):
                 if r != self.rank:
                     buf[r * self.chunk:(r + 1) * self.chunk].copy_(p)
