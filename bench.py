@@ -197,11 +197,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
+    # NBODY_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo instead of RCCL -- runs the multi-rank
+    # control flow on a one-GPU box (RCCL wants one GPU per rank); its numbers mean nothing
+    rehearsal = os.environ.get("NBODY_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     nb = load_package()
 
     # ---- headline: Barnes-Hut, galaxy collision N = 5M ----
@@ -272,7 +280,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": ms_per_step / PUBLISHED_MS,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL (all ranks on one GPU, gloo): not a measurement",
         "config": {
             "workload": "galaxy collision N=%d Barnes-Hut theta=0.5, 2-D (BASELINE.json configs[3]); forces FP32, "
                         "state and integration FP64" % args.bh_n,
