@@ -30,6 +30,8 @@ struct BhBuffers {
     uint32_t *hist_totals = nullptr;  // 256: keys per digit of the current pass
     int sort_blocks = 0;
     double *leaf_sum = nullptr;   // 4 doubles per sorted body: sums over the run of equal keys starting there
+    uint32_t *chunk_info = nullptr;  // per 64 sorted bodies: first lane that starts a run (64: none) |
+                                     // lane where the run that goes on into the next chunk starts (0xff: none) << 8
     float4 *posm_s = nullptr;     // per sorted body {x, y, m, radius} in internal units
     uint4 *node_meta = nullptr;   // first body, body count, first child, child count | cell level << 8
     uint4 *split = nullptr;       // per frontier slot: the three quadrant boundaries and child count
@@ -94,6 +96,10 @@ int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node
 size_t target_list_blocks(int n);
 int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int t1, uint32_t *tblock, uint32_t *tlist,
                    uint32_t *tcount);
+// Second half of the leaf pass: adds to every run of equal keys that crosses 64-body chunk
+// boundaries the parts its chunks left in leaf_sum (dims 2: slots of 4 doubles {3 sums, max
+// radius}; 3: slots of 6 doubles {4 sums, max radius, -}); chunk_info: see nb_dev.h.
+int leaf_finish(hipStream_t s, const uint32_t *chunk_info, int n, double *leaf_sum, int dims);
 // counters[2] = nodes, [3] = levels; *levels_host = levels (pinned host word).
 int bh_finish(hipStream_t s, const uint32_t *level_start, unsigned long long *counters, uint32_t *levels_host);
 

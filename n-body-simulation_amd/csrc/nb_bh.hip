@@ -856,14 +856,16 @@ __device__ __forceinline__ void store_node(const ComArgs &a, uint32_t u, const u
 // Sums over every run of bodies with one key (= every leaf with several bodies), left at the
 // run's first sorted position as {sum m x, sum m y, sum m, max radius}.  One wave per 64
 // consecutive sorted bodies: a segmented scan inside the wave gives the runs that end in its
-// chunk; a run that goes on past the chunk is finished by the same wave, 64 bodies at a time
-// (the waves of the chunks it crosses skip those bodies).  The order of the additions is fixed
-// by the positions alone, so the sums are reproducible.
+// chunk; of a run that crosses chunk boundaries every chunk leaves its part (the chunk where it
+// starts at the run's first position, the others in their own first slot) and k_leaf_finish adds
+// them up.  The order of the additions is fixed by the positions alone, so the sums are
+// reproducible.
 // The same pass writes every body's float record {x, y, m, radius} in sorted order (the
 // traversal's targets and the one-body leaves), since it reads exactly what that needs.
 __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const uint32_t *idx, int n, const double2 *pos,
                                                    const double *mass, const double *radius, const double *box,
-                                                   double inv_len, double inv_mass, float4 *posm_s, double *leaf_sum)
+                                                   double inv_len, double inv_mass, float4 *posm_s, double *leaf_sum,
+                                                   uint32_t *chunk_info)
 {
     const double ox = 0.5 * (box[0] + box[2]), oy = 0.5 * (box[1] + box[3]);  // this step's origin
     const int lane = lane_id();
@@ -886,8 +888,33 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
                                 (float)(rm * inv_len));
     }
     const uint64_t heads = __builtin_amdgcn_ballot_w64(valid && (k == 0 || key != prev));
-    if (heads == 0ull)
-        return;  // the whole chunk lies inside a run that started earlier: that run's wave sums it
+    // The bodies before the chunk's first head continue a run that started in an earlier chunk:
+    // their sums go to the chunk's first slot (no run starts there, so nothing else uses it), and
+    // k_leaf_finish adds them to that run.
+    const int first_head = heads ? (int)__builtin_ctzll(heads) : 64;
+    if (first_head > 0) {
+        const bool in_head = valid && lane < first_head;
+        double hm = in_head ? sm : 0.0, hx = in_head ? sx : 0.0, hy = in_head ? sy : 0.0, hr = in_head ? rm : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            hm += __shfl_xor(hm, o);
+            hx += __shfl_xor(hx, o);
+            hy += __shfl_xor(hy, o);
+            hr = fmax(hr, __shfl_xor(hr, o));
+        }
+        if (lane == 0) {
+            double *o = leaf_sum + 4 * (size_t)chunk;
+            o[0] = hx;
+            o[1] = hy;
+            o[2] = hm;
+            o[3] = hr;
+        }
+    }
+    if (heads == 0ull) {
+        if (lane == 0)
+            chunk_info[chunk >> 6] = 64u | (LEAF_NO_OWNER << 8);
+        return;  // the whole chunk lies inside a run that started earlier
+    }
     // first lane of this lane's run, if the run starts in this chunk
     const uint64_t upto = heads & ((2ull << lane) - 1ull);
     const int start = upto ? 63 - __builtin_clzll(upto) : -1;
@@ -916,42 +943,121 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
         o[2] = sm;
         o[3] = rm;
     }
+    // The run of the chunk's last body, when it started here and goes on: its part inside the
+    // chunk is left at its start, and k_leaf_finish adds the parts of the chunks it crosses.
     const int start63 = __shfl(start, 63);
-    if (goes_on && start63 >= 0) {
-        // every lane adds up the bodies it meets (position tail + lane, + 64, ...) until the
-        // run ends; one fold across the wave at the end
-        double pm = 0.0, px = 0.0, py = 0.0, pr = 0.0;
-        for (int base = tail; base < n; base += 64) {
-            const int kk = base + lane;
-            const bool in = kk < n && keys[kk] == last_key;
-            if (in) {
-                const uint32_t o = idx[kk];
-                const double2 p = pos[o];
-                const double m = mass[o];
-                pm += m;
-                px += p.x * m;
-                py += p.y * m;
-                pr = fmax(pr, radius[o]);
+    const bool owner = goes_on && start63 >= 0;
+    if (owner && lane == 63) {
+        double *o = leaf_sum + 4 * (size_t)(chunk + start63);
+        o[0] = sx;
+        o[1] = sy;
+        o[2] = sm;
+        o[3] = rm;
+    }
+    if (lane == 0)
+        chunk_info[chunk >> 6] = (uint32_t)first_head | ((owner ? (uint32_t)start63 : LEAF_NO_OWNER) << 8);
+}
+
+// Finishes the runs that cross chunk boundaries.  A run's parts are: what the chunk where it
+// starts left at the run's first position, the first slot of every chunk wholly inside the run (no
+// head), and the first slot of the chunk where it ends (the bodies before that chunk's first
+// head).  One thread per chunk: the thread of a chunk whose last run goes on adds the parts of the
+// next LEAF_SHORT chunks itself, which finishes the runs of a few hundred bodies (leaves of ~130
+// bodies are the rule when the tree is closed at level 9: about every second chunk owns a run).
+// A run that is longer than that -- the core of a collapsed disc inside one closed cell holds tens
+// of thousands of bodies -- is summed by the whole wave, 64 chunks a round.  (Left to one wave
+// walking the bodies 64 at a time, such a run took longer than the rest of the pass: 0.09 ->
+// 0.49 ms.)  The order of the additions depends on the positions alone.
+// A slot of leaf_sum holds STRIDE doubles: NSUM sums, then the largest radius.
+constexpr int LEAF_SHORT = 4;
+
+template <int NSUM, int STRIDE>
+__global__ __launch_bounds__(256) void k_leaf_finish(const uint32_t *chunk_info, int nchunks, double *leaf_sum)
+{
+    const int lane = lane_id();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mine = c < nchunks ? chunk_info[c] : (LEAF_NO_OWNER << 8);
+    const bool own = (mine >> 8) != LEAF_NO_OWNER;
+    double ps[NSUM], pr = 0.0;
+#pragma unroll
+    for (int v = 0; v < NSUM; ++v)
+        ps[v] = 0.0;
+    bool open = own;  // the end of the run is not found yet
+#pragma unroll 1
+    for (int it = 1; it <= LEAF_SHORT; ++it) {
+        if (__builtin_amdgcn_ballot_w64(open) == 0ull)
+            break;
+        const int cc = c + it;
+        // a chunk past the end ends the run like a chunk that starts with a head
+        const uint32_t fh = (open && cc < nchunks) ? (chunk_info[cc] & 0xffu) : 0u;
+        if (open && fh > 0u) {
+            const double *p = leaf_sum + (size_t)STRIDE * ((size_t)cc * 64);
+#pragma unroll
+            for (int v = 0; v < NSUM; ++v)
+                ps[v] += p[v];
+            pr = fmax(pr, p[NSUM]);
+        }
+        open = open && fh == 64u;
+    }
+    if (own && !open) {
+        double *t = leaf_sum + (size_t)STRIDE * ((size_t)c * 64 + (mine >> 8));
+#pragma unroll
+        for (int v = 0; v < NSUM; ++v)
+            t[v] += ps[v];
+        t[NSUM] = fmax(t[NSUM], pr);
+    }
+    uint64_t owners = __builtin_amdgcn_ballot_w64(own && open);  // the long runs
+    while (owners != 0ull) {
+        const int o = (int)__builtin_ctzll(owners);
+        owners &= owners - 1ull;
+        const int c0 = c - lane + o;
+        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)(mine >> 8), o);
+#pragma unroll
+        for (int v = 0; v < NSUM; ++v)
+            ps[v] = 0.0;
+        pr = 0.0;
+        for (int base = c0 + 1;; base += 64) {
+            const int cc = base + lane;
+            const uint32_t fh = cc < nchunks ? (chunk_info[cc] & 0xffu) : 0u;
+            const uint64_t term = __builtin_amdgcn_ballot_w64(fh < 64u);
+            const int e = term ? (int)__builtin_ctzll(term) : 64;
+            if (lane <= e && fh > 0u) {
+                const double *p = leaf_sum + (size_t)STRIDE * ((size_t)cc * 64);
+#pragma unroll
+                for (int v = 0; v < NSUM; ++v)
+                    ps[v] += p[v];
+                pr = fmax(pr, p[NSUM]);
             }
-            if (__builtin_amdgcn_ballot_w64(in) != ~0ull)
-                break;  // the run ended inside these 64
+            if (term != 0ull)
+                break;
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            pm += __shfl_xor(pm, o);
-            px += __shfl_xor(px, o);
-            py += __shfl_xor(py, o);
-            pr = fmax(pr, __shfl_xor(pr, o));
+        for (int q = 32; q > 0; q >>= 1) {
+#pragma unroll
+            for (int v = 0; v < NSUM; ++v)
+                ps[v] += __shfl_xor(ps[v], q);
+            pr = fmax(pr, __shfl_xor(pr, q));
         }
-        const double hx = __shfl(sx, 63), hy = __shfl(sy, 63), hm = __shfl(sm, 63), hr = __shfl(rm, 63);
         if (lane == 0) {
-            double *o = leaf_sum + 4 * (size_t)(chunk + start63);
-            o[0] = hx + px;
-            o[1] = hy + py;
-            o[2] = hm + pm;
-            o[3] = fmax(hr, pr);
+            double *t = leaf_sum + (size_t)STRIDE * ((size_t)c0 * 64 + st);
+#pragma unroll
+            for (int v = 0; v < NSUM; ++v)
+                t[v] += ps[v];
+            t[NSUM] = fmax(t[NSUM], pr);
         }
     }
+}
+
+int leaf_finish(hipStream_t s, const uint32_t *chunk_info, int n, double *leaf_sum, int dims)
+{
+    const int nchunks = (n + 63) / 64;
+    const dim3 grid((nchunks + 255) / 256);
+    if (dims == 3)
+        hipLaunchKernelGGL((k_leaf_finish<4, 6>), grid, dim3(256), 0, s, chunk_info, nchunks, leaf_sum);
+    else
+        hipLaunchKernelGGL((k_leaf_finish<3, 4>), grid, dim3(256), 0, s, chunk_info, nchunks, leaf_sum);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
 }
 
 // Centres of mass, masses and traversal records of the nodes of tree level d (children first:
@@ -1051,7 +1157,8 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.cth = a.collision_th;
     c.bucket = a.bucket_depth > 0 ? 1 : 0;
     hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[b.sorted], b.idx[b.sorted], a.n, a.pos,
-                       a.mass, a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum);
+                       a.mass, a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum, b.chunk_info);
+    NB_TRY(leaf_finish(s, b.chunk_info, a.n, b.leaf_sum, 2));
     // levels beyond the ones the build launched per-level kernels for: one block, one launch
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
@@ -1617,6 +1724,7 @@ int bh_alloc(BhBuffers &b, int n)
     NB_TRY(dev_alloc(b.box, 4));
     NB_TRY(dev_alloc(b.cut, 4));
     NB_TRY(dev_alloc(b.leaf_sum, 4 * (size_t)n));
+    NB_TRY(dev_alloc(b.chunk_info, (size_t)n / 64 + 2));
     NB_TRY(dev_alloc(b.bbox_part, 4 * BBOX_BLOCKS));
     for (int k = 0; k < 2; ++k) {
         NB_TRY(dev_alloc(b.keys[k], (size_t)n));
@@ -1651,6 +1759,7 @@ void bh_free(BhBuffers &b)
     (void)hipFree(b.box);
     (void)hipFree(b.cut);
     (void)hipFree(b.leaf_sum);
+    (void)hipFree(b.chunk_info);
     (void)hipFree(b.bbox_part);
     for (int k = 0; k < 2; ++k) {
         (void)hipFree(b.keys[k]);

@@ -249,7 +249,7 @@ __device__ __forceinline__ void store_node3(const Com3Args &a, uint32_t u, const
 __global__ __launch_bounds__(256) void k_leaf_sums3(const uint64_t *keys, const uint32_t *idx, int n, const double *pos,
                                                     const double *mass, const double *radius, const double *box,
                                                     double inv_len, double inv_mass, float4 *posm_s, float *rad_s,
-                                                    double *leaf_sum)
+                                                    double *leaf_sum, uint32_t *chunk_info)
 {
     const double ox = 0.5 * (box[0] + box[2]), oy = 0.5 * (box[1] + box[3]), oz = 0.5 * (box[4] + box[5]);
     const int lane = lane_id();
@@ -274,8 +274,35 @@ __global__ __launch_bounds__(256) void k_leaf_sums3(const uint64_t *keys, const 
         rad_s[k] = (float)(rm * inv_len);
     }
     const uint64_t heads = __builtin_amdgcn_ballot_w64(valid && (k == 0 || key != prev));
-    if (heads == 0ull)
-        return;  // the whole chunk lies inside a run that started earlier: that run's wave sums it
+    // the bodies before the chunk's first head continue a run from an earlier chunk: their sums
+    // go to the chunk's first slot (no run starts there) for leaf_finish to add to that run
+    const int first_head = heads ? (int)__builtin_ctzll(heads) : 64;
+    if (first_head > 0) {
+        const bool in_head = valid && lane < first_head;
+        double hm = in_head ? sm : 0.0, hx = in_head ? sx : 0.0, hy = in_head ? sy : 0.0, hz = in_head ? sz : 0.0,
+               hr = in_head ? rm : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            hm += __shfl_xor(hm, o);
+            hx += __shfl_xor(hx, o);
+            hy += __shfl_xor(hy, o);
+            hz += __shfl_xor(hz, o);
+            hr = fmax(hr, __shfl_xor(hr, o));
+        }
+        if (lane == 0) {
+            double *o = leaf_sum + 6 * (size_t)chunk;
+            o[0] = hx;
+            o[1] = hy;
+            o[2] = hz;
+            o[3] = hm;
+            o[4] = hr;
+        }
+    }
+    if (heads == 0ull) {
+        if (lane == 0)
+            chunk_info[chunk >> 6] = 64u | (LEAF_NO_OWNER << 8);
+        return;  // the whole chunk lies inside a run that started earlier
+    }
     const uint64_t upto = heads & ((2ull << lane) - 1ull);
     const int start = upto ? 63 - __builtin_clzll(upto) : -1;
     const int dist = start >= 0 ? lane - start : 0;
@@ -304,42 +331,20 @@ __global__ __launch_bounds__(256) void k_leaf_sums3(const uint64_t *keys, const 
         o[3] = sm;
         o[4] = rm;
     }
+    // the run of the chunk's last body, when it started here and goes on: its part inside the
+    // chunk stays at its start, leaf_finish adds the parts of the chunks it crosses
     const int start63 = __shfl(start, 63);
-    if (goes_on && start63 >= 0) {
-        double pm = 0.0, px = 0.0, py = 0.0, pz = 0.0, pr = 0.0;
-        for (int base = tail; base < n; base += 64) {
-            const int kk = base + lane;
-            const bool in = kk < n && keys[kk] == last_key;
-            if (in) {
-                const uint32_t o = idx[kk];
-                const double m = mass[o];
-                pm += m;
-                px += pos[3 * (size_t)o] * m;
-                py += pos[3 * (size_t)o + 1] * m;
-                pz += pos[3 * (size_t)o + 2] * m;
-                pr = fmax(pr, radius[o]);
-            }
-            if (__builtin_amdgcn_ballot_w64(in) != ~0ull)
-                break;  // the run ended inside these 64
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            pm += __shfl_xor(pm, o);
-            px += __shfl_xor(px, o);
-            py += __shfl_xor(py, o);
-            pz += __shfl_xor(pz, o);
-            pr = fmax(pr, __shfl_xor(pr, o));
-        }
-        const double hx = __shfl(sx, 63), hy = __shfl(sy, 63), hz = __shfl(sz, 63), hm = __shfl(sm, 63), hr = __shfl(rm, 63);
-        if (lane == 0) {
-            double *o = leaf_sum + 6 * (size_t)(chunk + start63);
-            o[0] = hx + px;
-            o[1] = hy + py;
-            o[2] = hz + pz;
-            o[3] = hm + pm;
-            o[4] = fmax(hr, pr);
-        }
+    const bool owner = goes_on && start63 >= 0;
+    if (owner && lane == 63) {
+        double *o = leaf_sum + 6 * (size_t)(chunk + start63);
+        o[0] = sx;
+        o[1] = sy;
+        o[2] = sz;
+        o[3] = sm;
+        o[4] = rm;
     }
+    if (lane == 0)
+        chunk_info[chunk >> 6] = (uint32_t)first_head | ((owner ? (uint32_t)start63 : LEAF_NO_OWNER) << 8);
 }
 
 // Centres of mass, masses and traversal records of the nodes of tree level d (children first).
@@ -435,7 +440,8 @@ int bh3_com(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     c.theta = a.theta;
     c.cth = a.collision_th;
     hipLaunchKernelGGL(k_leaf_sums3, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[0], b.idx[0], a.n, a.pos, a.mass,
-                       a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.rad_s, b.leaf_sum);
+                       a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.rad_s, b.leaf_sum, b.chunk_info);
+    NB_TRY(leaf_finish(s, b.chunk_info, a.n, b.leaf_sum, 3));
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com3, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
     // the top levels hold a few hundred nodes at most (8^d): one block does them in one launch
@@ -889,6 +895,7 @@ int bh3_alloc(Bh3Buffers &b, int n)
     NB_TRY(dev_alloc(b.hist, sort_hist_words(n)));
     NB_TRY(dev_alloc(b.hist_totals, 256));
     NB_TRY(dev_alloc(b.leaf_sum, 6 * (size_t)n));
+    NB_TRY(dev_alloc(b.chunk_info, (size_t)n / 64 + 2));
     NB_TRY(dev_alloc(b.posm_s, (size_t)n));
     NB_TRY(dev_alloc(b.rad_s, (size_t)n));
     NB_TRY(dev_alloc(b.node_meta, b.node_cap));
@@ -926,6 +933,7 @@ void bh3_free(Bh3Buffers &b)
     (void)hipFree(b.hist);
     (void)hipFree(b.hist_totals);
     (void)hipFree(b.leaf_sum);
+    (void)hipFree(b.chunk_info);
     (void)hipFree(b.posm_s);
     (void)hipFree(b.rad_s);
     (void)hipFree(b.node_meta);

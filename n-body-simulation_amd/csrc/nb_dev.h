@@ -49,6 +49,10 @@ static __device__ __forceinline__ int block_sum_256(int v)
     return wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3];
 }
 
+// chunk_info word of the leaf pass (per 64 sorted bodies): first lane that starts a run of equal
+// keys (64: none) | lane where the run that goes on into the next chunk starts << 8, or:
+constexpr unsigned LEAF_NO_OWNER = 0xffu;  // no run of this chunk goes on into the next
+
 // The radix sort (sort_pairs) orders key << 2 by eight 8-bit digits, lowest first.  Keys whose
 // digits fill only the top `used_bits` bits of that word are zero below, and the passes over
 // those zero digits would move nothing: this is the first pass that has work.

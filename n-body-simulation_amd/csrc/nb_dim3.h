@@ -61,6 +61,7 @@ struct Bh3Buffers {
     uint32_t *cut = nullptr;      // [0] first closed level (32: none), [1] key levels, [2] first sort pass
     uint32_t *hist = nullptr, *hist_totals = nullptr;
     double *leaf_sum = nullptr;   // 6 doubles per sorted body: sum m x, m y, m z, sum m, max radius, -
+    uint32_t *chunk_info = nullptr;  // per 64 sorted bodies, see nb_dev.h
     float4 *posm_s = nullptr;     // per sorted body {x, y, z, m}, internal units
     float *rad_s = nullptr;       // per sorted body: radius
     uint4 *node_meta = nullptr;   // first body, body count, first child, child count | cell level << 8

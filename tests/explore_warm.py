@@ -1,5 +1,6 @@
-"""Step time of the headline Barnes-Hut workload in consecutive chunks of steps after a cold start
-(tuning aid, not a test): shows how many steps the GPU takes to reach its steady clocks."""
+"""Does the order of the bodies inside the closed leaves matter?  (tuning aid, not a test)
+The headline workload after 300 steps, timed before and after nb_refresh_order, which re-sorts the
+exchange order -- the order the stable sort keeps inside a leaf -- by the current positions."""
 import sys
 import time
 
@@ -11,11 +12,15 @@ n = 5000000
 b = nb.init_scenario(nb.COLLISION, n, 12345)
 with nb.NBodySim(n, nb.BARNES_HUT) as sim:
     sim.set_bodies(b)
+    sim.update(300)
     sim.sync()
-    out = []
-    for chunk in (3, 5, 5, 5, 5, 5, 5, 5, 5, 10, 10):
+    for tag in ("before", "after refresh_order", "again"):
+        sim.set_stage_timing(True, counters=False)
         t = time.perf_counter()
-        sim.update(chunk)
+        sim.update(20)
         sim.sync()
-        out.append("%d: %.3f" % (chunk, (time.perf_counter() - t) / chunk * 1e3))
-print("BH N=%d ms/step per chunk of steps  " % n + " | ".join(out), flush=True)
+        dt = (time.perf_counter() - t) / 20 * 1e3
+        print(tag, "%.3f ms/step" % dt, " ".join("%s=%.3f" % kv for kv in sim.stage_ms().items() if kv[1] > 0), flush=True)
+        sim.set_stage_timing(False, counters=False)
+        if tag == "before":
+            sim.refresh_order()

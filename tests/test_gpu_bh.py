@@ -467,3 +467,44 @@ def test_deep_clustered_tree_stresses_the_traversal_stack(nb, oracle, dims):
     err = rel_err(acc, ref)
     assert np.median(err) <= 5e-6 and np.quantile(err, 0.99) <= 1e-4 and err.max() <= 2e-3, (
         np.quantile(err, [0.5, 0.99, 0.999]), err.max())
+
+
+def test_leaf_sums_of_runs_that_cross_chunk_boundaries(nb, oracle):
+    """Bodies that share a cell nobody opens share a leaf; its mass, centre of mass and largest radius
+    are summed by waves of 64 sorted bodies, and a leaf of more than 64 bodies is put together from the
+    parts of the chunks it crosses.  Clumps of many sizes (1 .. 5000 bodies, so runs start and end at
+    every position of a chunk) against numpy sums, and the accelerations against the oracle's full tree."""
+    rng_ = np.random.default_rng(5)
+    sizes = [1, 2, 63, 64, 65, 127, 128, 129, 191, 193, 640, 1000, 5000, 4097, 3]
+    n = sum(sizes) + 1
+    b = oracle.scenario(0, n, 21)
+    at = 0
+    for j, sz in enumerate(sizes):
+        # clump j: inside one cell of 1/1024 of the box (the tree closes at level 8 or 9)
+        centre = np.array([(-4.0 + 0.55 * j) * 1.0e11 + 3.1e8, (-3.0 + 0.41 * j) * 1.0e11 + 1.7e8])
+        b["pos"][at:at + sz] = centre + rng_.uniform(-2.0e8, 2.0e8, size=(sz, 2))
+        b["radius"][at:at + sz] = rng_.uniform(1.0e3, 5.0e4, size=sz)
+        b["mass"][at:at + sz] *= rng_.uniform(0.5, 2.0, size=sz)
+        at += sz
+    sim, acc = run_accel(nb, b)
+    bx = exchange_bodies(sim, b)
+    ls, rng, ch, com = tree_arrays(nb, sim)
+    idx = sim.debug(nb.DBG_SORTED_IDX, np.uint32, n)
+    closed, levels = (int(v) for v in sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2))
+    assert closed <= 10
+    m, p = bx["mass"][idx], bx["pos"][idx]
+    leaves = np.flatnonzero((ch[:, 1] == 0) & (rng[:, 1] > 1))
+    seen = set()
+    for u in leaves:
+        first, count = (int(v) for v in rng[u])
+        mm = m[first:first + count]
+        assert com[u, 2] == pytest.approx(mm.sum(), rel=1e-13)
+        assert com[u, 0] == pytest.approx((mm * p[first:first + count, 0]).sum() / mm.sum(), rel=1e-12, abs=1e-3)
+        assert com[u, 1] == pytest.approx((mm * p[first:first + count, 1]).sum() / mm.sum(), rel=1e-12, abs=1e-3)
+        seen.add(count)
+    # (a clump that straddles a cell boundary makes two leaves, so only the overall picture is fixed)
+    assert max(seen) >= 2000 and sum(c > 64 for c in seen) >= 6 and sum(c <= 64 for c in seen) >= 1
+    sim.close()
+    ref = oracle.bh_accel(b)
+    dyn = b["is_dynamic"] != 0
+    assert rel_err(acc[dyn], ref[dyn]).max() <= ACC_EXPECTED
