@@ -1189,6 +1189,9 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 #ifndef NB_TR_HIGH
 #define NB_TR_HIGH 64
 #endif
+#ifndef NB_TR_FULL_UNROLL
+#define NB_TR_FULL_UNROLL 2
+#endif
 constexpr int TR_ENTRIES = NB_TR_ENTRIES;
 constexpr int TR_BATCH = 4 * TR_ENTRIES;  // most nodes a round can hold
 constexpr int TR_HIGH = NB_TR_HIGH;
@@ -1296,8 +1299,9 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
     int max_top = 0;
 
     int top = 0;
+    // every lane the wave computes a force for; a node visited for all of them needs no lane mask
+    const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
     {
-        const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
         if (m0 != 0ull) {
             if (lane == 0) {
                 snode[0] = 1u;  // the root as a group of one
@@ -1349,8 +1353,11 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         const uint64_t bodym = __builtin_amdgcn_ballot_w64((int)__float_as_uint(rec.w) < 0) & cmask;
         const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~bodym;
         const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < rec.w * 0.999f) & farm_all;
-        const uint64_t surem = __builtin_amdgcn_ballot_w64(dmin2 > rec.w * 1.001f) & farm_all;
-        const uint64_t farcm = farm_all & ~(openm | surem);
+        const uint64_t sureall = __builtin_amdgcn_ballot_w64(dmin2 > rec.w * 1.001f) & farm_all;
+        const uint64_t farcm = farm_all & ~(openm | sureall);
+        // accepted by every lane AND visited for all of the wave's lanes: the plain force loop
+        const uint64_t fullm = sureall & __builtin_amdgcn_ballot_w64(um == m0);
+        const uint64_t surem = sureall & ~fullm;
         const uint64_t nearm = cmask & ~(bodym | farm_all);
         if (openm != 0ull) {
             // one entry per opened node that has children
@@ -1374,15 +1381,18 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         // Stage the rest in LDS, by kind: every lane then reads entry j with the same address (an
         // LDS broadcast), which keeps the per-node data off the vector ALU's lane-read path, and
         // each kind of node gets a loop without the other kinds' code.
-        const int nsure = (int)__popcll(surem), nfar = nsure + (int)__popcll(farcm), ncell = nfar + (int)__popcll(nearm);
+        const int nfull = (int)__popcll(fullm), nsure = nfull + (int)__popcll(surem);
+        const int nfar = nsure + (int)__popcll(farcm), ncell = nfar + (int)__popcll(nearm);
         const int cstaged = ncell + (int)__popcll(bodym);
         int slot_j;
         {
+            const int r_full = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fullm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fullm, 0u));
             const int r_sure = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(surem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)surem, 0u));
             const int r_far = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(farcm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)farcm, 0u));
             const int r_near = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nearm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nearm, 0u));
             const int r_body = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bodym >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bodym, 0u));
-            slot_j = r_sure;
+            slot_j = r_full;
+            slot_j = __builtin_amdgcn_inverse_ballot_w64(surem) ? nfull + r_sure : slot_j;
             slot_j = __builtin_amdgcn_inverse_ballot_w64(farcm) ? nsure + r_far : slot_j;
             slot_j = __builtin_amdgcn_inverse_ballot_w64(nearm) ? nfar + r_near : slot_j;
             slot_j = __builtin_amdgcn_inverse_ballot_w64(bodym) ? ncell + r_body : slot_j;
@@ -1475,8 +1485,26 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                 n_visit += 1;
             }
         };
+        // ---- cells every lane accepts and that are visited for every lane the wave computes a
+        // force for (6 of 7 such cells at N = 5M): only the force, no lane mask.  A lane outside m0
+        // is a static or padding lane and sums values nobody reads.  Unrolled by 2 only: the
+        // compiler's own choice (8) costs 16 registers, i.e. two of the eight waves per SIMD. ----
+#pragma unroll NB_TR_FULL_UNROLL
+        for (int j = 0; j < nfull; ++j) {
+            const uint4 r = batch[j][0];
+            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi;
+            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+            const float sc = force_scale<MODE>(d2, __uint_as_float(r.z), eps2, eps3);
+            fx = __builtin_fmaf(dx, sc, fx);
+            fy = __builtin_fmaf(dy, sc, fy);
+            if (STATS) {
+                n_eval += (unsigned long long)__popcll(m0);
+                n_acc += (unsigned long long)__popcll(m0);
+                n_visit += 1;
+            }
+        }
         // ---- cells every lane accepts: only the force, for the lanes the cell is visited for ----
-        for (int j = 0; j < nsure; ++j) {
+        for (int j = nfull; j < nsure; ++j) {
             const uint4 r = batch[j][0];
             const uint2 q = *(const uint2 *)&batch[j][1];
             const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);

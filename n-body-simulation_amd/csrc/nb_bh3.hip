@@ -566,8 +566,9 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
     int max_top = 0;
 
     int top = 0;
+    // every lane the wave computes a force for; a node visited for all of them needs no lane mask
+    const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
     {
-        const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
         if (m0 != 0ull) {
             if (lane == 0) {
                 snode[0] = 1u;  // the root as a group of one
@@ -619,8 +620,11 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
         const uint64_t bodym = __builtin_amdgcn_ballot_w64((int)aux.x < 0) & cmask;
         const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~bodym;
         const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < nw * 0.999f) & farm_all;
-        const uint64_t surem = __builtin_amdgcn_ballot_w64(dmin2 > nw * 1.001f) & farm_all;
-        const uint64_t farcm = farm_all & ~(openm | surem);
+        const uint64_t sureall = __builtin_amdgcn_ballot_w64(dmin2 > nw * 1.001f) & farm_all;
+        const uint64_t farcm = farm_all & ~(openm | sureall);
+        // accepted by every lane AND visited for all of the wave's lanes: the plain force loop
+        const uint64_t fullm = sureall & __builtin_amdgcn_ballot_w64(um == m0);
+        const uint64_t surem = sureall & ~fullm;
         const uint64_t nearm = cmask & ~(bodym | farm_all);
         if (openm != 0ull) {
             // one entry per opened node that has children
@@ -641,9 +645,11 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
             }
         }
         // stage the rest in LDS by kind; every lane then reads entry j at the same address
-        const int nsure = (int)__popcll(surem), nfar = nsure + (int)__popcll(farcm), ncell = nfar + (int)__popcll(nearm);
+        const int nfull = (int)__popcll(fullm), nsure = nfull + (int)__popcll(surem);
+        const int nfar = nsure + (int)__popcll(farcm), ncell = nfar + (int)__popcll(nearm);
         const int cstaged = ncell + (int)__popcll(bodym);
-        int slot_j = (int)mbcnt64(surem);
+        int slot_j = (int)mbcnt64(fullm);
+        slot_j = __builtin_amdgcn_inverse_ballot_w64(surem) ? nfull + (int)mbcnt64(surem) : slot_j;
         slot_j = __builtin_amdgcn_inverse_ballot_w64(farcm) ? nsure + (int)mbcnt64(farcm) : slot_j;
         slot_j = __builtin_amdgcn_inverse_ballot_w64(nearm) ? nfar + (int)mbcnt64(nearm) : slot_j;
         slot_j = __builtin_amdgcn_inverse_ballot_w64(bodym) ? ncell + (int)mbcnt64(bodym) : slot_j;
@@ -725,8 +731,26 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
                 n_visit += 1;
             }
         };
+        // ---- cells every lane accepts and that are visited for every lane the wave computes a
+        // force for: only the force, no lane mask (a lane outside m0 is a static or padding lane
+        // and sums values nobody reads).  Unrolled by 2 only: more costs registers, i.e. waves. ----
+#pragma unroll 2
+        for (int j = 0; j < nfull; ++j) {
+            const uint4 r = batch[j][0];
+            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi, dz = __uint_as_float(r.z) - zi;
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const float sc = force_scale3<MODE>(d2, __uint_as_float(r.w), eps2, eps3);
+            fx = __builtin_fmaf(dx, sc, fx);
+            fy = __builtin_fmaf(dy, sc, fy);
+            fz = __builtin_fmaf(dz, sc, fz);
+            if (STATS) {
+                n_eval += (unsigned long long)__popcll(m0);
+                n_acc += (unsigned long long)__popcll(m0);
+                n_visit += 1;
+            }
+        }
         // ---- cells every lane accepts: only the force, for the lanes the cell is visited for ----
-        for (int j = 0; j < nsure; ++j) {
+        for (int j = nfull; j < nsure; ++j) {
             const uint4 r = batch[j][0];
             const uint2 q = *(const uint2 *)&batch[j][1];
             const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
