@@ -231,12 +231,57 @@ __global__ __launch_bounds__(256) void k_sort_count(const uint64_t *keys, int n,
     __shared__ uint32_t h[SORT_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const int base = blockIdx.x * SORT_TILE;
+    // Every thread takes SORT_ITEMS consecutive keys.  Keys that follow each other mostly share
+    // the digit (the bodies arrive in a spatial order, and the upper passes see nearly sorted
+    // keys), so a thread adds a whole run of equal digits with one LDS atomic, and a wave whose
+    // keys all have one digit adds them with a single one: one atomic per key would serialise
+    // on a handful of counters.
+    const int i0 = blockIdx.x * SORT_TILE + threadIdx.x * SORT_ITEMS;
+    uint32_t d[SORT_ITEMS];
+    int cnt = n - i0;  // keys of this thread
+    cnt = cnt < 0 ? 0 : (cnt > SORT_ITEMS ? SORT_ITEMS : cnt);
+    if (cnt == SORT_ITEMS) {
+        static_assert(SORT_ITEMS % 2 == 0, "two keys per 16-byte load");
+        const ulonglong2 *src = (const ulonglong2 *)(keys + i0);  // i0 is a multiple of SORT_ITEMS
 #pragma unroll
-    for (int it = 0; it < SORT_ITEMS; ++it) {
-        int i = base + it * 256 + threadIdx.x;
-        if (i < n)
-            atomicAdd(&h[sort_digit(keys[i], pass)], 1u);
+        for (int it = 0; it < SORT_ITEMS / 2; ++it) {
+            const ulonglong2 v = src[it];
+            d[2 * it] = sort_digit(v.x, pass);
+            d[2 * it + 1] = sort_digit(v.y, pass);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; ++it)
+            d[it] = it < cnt ? sort_digit(keys[i0 + it], pass) : 0u;
+    }
+    bool one_run = true;
+#pragma unroll
+    for (int it = 1; it < SORT_ITEMS; ++it)
+        one_run = one_run && (it >= cnt || d[it] == d[0]);
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d[0]);
+    if (__builtin_amdgcn_ballot_w64(!(one_run && (cnt == 0 || d[0] == d0))) == 0ull) {
+        // the whole wave holds one digit
+        int c = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            c += __shfl_xor(c, o);
+        if ((threadIdx.x & 63) == 0 && c > 0)
+            atomicAdd(&h[d0], (uint32_t)c);
+    } else if (cnt > 0) {
+        uint32_t run_d = d[0], run = 1;
+#pragma unroll
+        for (int it = 1; it < SORT_ITEMS; ++it) {
+            if (it >= cnt)
+                break;
+            if (d[it] == run_d) {
+                run += 1;
+            } else {
+                atomicAdd(&h[run_d], run);
+                run_d = d[it];
+                run = 1;
+            }
+        }
+        atomicAdd(&h[run_d], run);
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
