@@ -329,18 +329,23 @@ __global__ __launch_bounds__(256) void k_scan_rows(uint32_t *hist, int nblk, uin
     if (pass < (int)cut[2])
         return;
     uint32_t *row = hist + (size_t)blockIdx.x * nblk;
-    uint32_t running = 0;
-    for (int base = 0; base < nblk; base += 256) {
-        const int i = base + threadIdx.x;
-        const int v = i < nblk ? (int)row[i] : 0;
-        int tile_total;
-        const int excl = block_excl_scan_256(v, tile_total);
-        if (i < nblk)
-            row[i] = running + (uint32_t)excl;
-        running += (uint32_t)tile_total;
+    // every thread sums a stretch of consecutive counts, one block scan over the 256 sums, then
+    // the stretch is rewritten with its running offsets
+    const int per = (nblk + 255) / 256;
+    const int beg = (int)threadIdx.x * per;
+    const int end = beg + per < nblk ? beg + per : nblk;
+    int sum = 0;
+    for (int i = beg; i < end; ++i)
+        sum += (int)row[i];
+    int total;
+    uint32_t run = (uint32_t)block_excl_scan_256(sum, total);
+    for (int i = beg; i < end; ++i) {
+        const uint32_t v = row[i];
+        row[i] = run;
+        run += v;
     }
     if (threadIdx.x == 0)
-        totals[blockIdx.x] = running;
+        totals[blockIdx.x] = (uint32_t)total;
 }
 
 // Stable scatter of one 8-bit digit.  Wave w of a block owns a contiguous chunk of
