@@ -89,8 +89,9 @@ int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], i
 size_t build_split_bytes(int bits);
 int level_blocks(int d, int bits, int nodes_per_block);  // grid of a per-level kernel (<= BH_SCAN_BLOCKS)
 int launched_levels(const uint32_t *levels_host);
+// When the tree is complete: counters[2] = nodes, [3] = levels; *levels_host = levels (pinned host word).
 int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node_meta, void *split, uint32_t *level_start,
-               uint32_t *bsum, unsigned long long *counters, int launched);
+               uint32_t *bsum, unsigned long long *counters, int launched, uint32_t *levels_host);
 // Sorted positions k whose body sorted_idx[k] lies in [t0, t1), ascending, into tlist (n words);
 // their number into *tcount; tblock: target_list_blocks(n) words of scratch.
 size_t target_list_blocks(int n);
@@ -100,8 +101,6 @@ int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int
 // boundaries the parts its chunks left in leaf_sum (dims 2: slots of 4 doubles {3 sums, max
 // radius}; 3: slots of 6 doubles {4 sums, max radius, -}); chunk_info: see nb_dev.h.
 int leaf_finish(hipStream_t s, const uint32_t *chunk_info, int n, double *leaf_sum, int dims);
-// counters[2] = nodes, [3] = levels; *levels_host = levels (pinned host word).
-int bh_finish(hipStream_t s, const uint32_t *level_start, unsigned long long *counters, uint32_t *levels_host);
 
 // Individual stages (also driven one by one by the stage tests through nb_step).
 int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a);

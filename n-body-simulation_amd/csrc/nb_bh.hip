@@ -470,7 +470,8 @@ int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // ------------------------------------------------------------------ 4 tree build
 
-__global__ void k_build_init(uint4 *node_meta, uint32_t *level_start, int n, unsigned long long *counters)
+// The empty tree: the root holds every body, no other level has a node yet.  (A block of >= 64 threads.)
+__device__ __forceinline__ void build_init(uint4 *node_meta, uint32_t *level_start, int n, unsigned long long *counters)
 {
     int t = threadIdx.x;
     if (t < BH_MAX_DEPTH + 2)
@@ -661,8 +662,8 @@ __device__ __forceinline__ void emit_children(uint4 *node_meta, uint32_t u, cons
 }
 
 template <int BITS>
-__global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4 *node_meta, Split<BITS> *split,
-                                                     const uint32_t *level_start, uint32_t *bsum, int d)
+__device__ __forceinline__ void build_count(const uint64_t *keys, uint4 *node_meta, Split<BITS> *split,
+                                            const uint32_t *level_start, uint32_t *bsum, int d)
 {
     uint32_t lbeg, m, cbeg, cend;
     level_chunk(level_start, d, lbeg, m, cbeg, cend);
@@ -702,8 +703,15 @@ __global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4
 }
 
 template <int BITS>
-__global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, const Split<BITS> *split, uint32_t *level_start,
-                                                    const uint32_t *bsum, int d)
+__global__ __launch_bounds__(256) void k_build_count(const uint64_t *keys, uint4 *node_meta, Split<BITS> *split,
+                                                     const uint32_t *level_start, uint32_t *bsum, int d)
+{
+    build_count<BITS>(keys, node_meta, split, level_start, bsum, d);
+}
+
+template <int BITS>
+__device__ __forceinline__ void build_emit(uint4 *node_meta, const Split<BITS> *split, uint32_t *level_start,
+                                           const uint32_t *bsum, int d)
 {
     uint32_t lbeg, m, cbeg, cend;
     level_chunk(level_start, d, lbeg, m, cbeg, cend);
@@ -737,12 +745,40 @@ __global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, const Spli
     }
 }
 
+template <int BITS>
+__global__ __launch_bounds__(256) void k_build_emit(uint4 *node_meta, const Split<BITS> *split, uint32_t *level_start,
+                                                    const uint32_t *bsum, int d)
+{
+    build_emit<BITS>(node_meta, split, level_start, bsum, d);
+}
+
+// The start of the build in ONE launch of one block: the empty tree, then levels 0 .. top - 1
+// (a single block is all these levels -- at most 2^BITS nodes -- get anyway).
+template <int BITS>
+__global__ __launch_bounds__(256) void k_build_top(const uint64_t *keys, uint4 *node_meta, Split<BITS> *split,
+                                                   uint32_t *level_start, uint32_t *bsum, int n,
+                                                   unsigned long long *counters, int top)
+{
+    build_init(node_meta, level_start, n, counters);
+    for (int d = 0; d < top; ++d) {
+        __threadfence_block();
+        __syncthreads();  // level_start[d + 1] and the level's nodes are written
+        build_count<BITS>(keys, node_meta, split, level_start, bsum, d);
+        __threadfence_block();
+        __syncthreads();  // bsum[0] and the splits are written
+        build_emit<BITS>(node_meta, split, level_start, bsum, d);
+    }
+}
+
 // Levels from d0 on, by ONE block: the host launches the per-level kernels only for as many
 // levels as the previous steps' trees had (plus a margin) and lets this kernel finish whatever
 // is left -- normally nothing, so it returns at once; a tree that grew deeper is still built
 // completely, just by fewer threads.
+// When the tree is complete it leaves the numbers of nodes and levels in counters[2], [3] and the
+// level count in *levels_host (host-visible: it sizes the next steps' launches).
 template <int BITS>
-__global__ __launch_bounds__(256) void k_build_tail(const uint64_t *keys, uint4 *node_meta, uint32_t *level_start, int d0)
+__global__ __launch_bounds__(256) void k_build_tail(const uint64_t *keys, uint4 *node_meta, uint32_t *level_start, int d0,
+                                                    unsigned long long *counters, uint32_t *levels_host)
 {
     for (int d = d0; d < BH_MAX_DEPTH - 2; ++d) {
         const uint32_t lbeg = level_start[d], m = level_start[d + 1] - lbeg;
@@ -766,6 +802,16 @@ __global__ __launch_bounds__(256) void k_build_tail(const uint64_t *keys, uint4 
             level_start[d + 2] = running;
         __threadfence_block();
         __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int levels = 0;
+        for (int d = 0; d < BH_MAX_DEPTH; ++d)
+            if (level_start[d + 1] > level_start[d])
+                levels = d + 1;
+        counters[2] = level_start[levels];
+        counters[3] = (unsigned long long)levels;
+        if (levels_host)
+            *levels_host = (uint32_t)levels;
     }
 }
 
@@ -795,28 +841,33 @@ int level_blocks(int d, int bits, int nodes_per_block)
     return blocks < BH_SCAN_BLOCKS ? blocks : BH_SCAN_BLOCKS;
 }
 
+constexpr int BUILD_TOP_LEVELS = 2;  // level_blocks() gives levels 0 and 1 one block
+
 template <int BITS>
 static void launch_build(hipStream_t s, const uint64_t *keys, int n, uint4 *node_meta, void *split, uint32_t *level_start,
-                         uint32_t *bsum, unsigned long long *counters, int launched)
+                         uint32_t *bsum, unsigned long long *counters, int launched, uint32_t *levels_host)
 {
-    hipLaunchKernelGGL(k_build_init, dim3(1), dim3(64), 0, s, node_meta, level_start, n, counters);
-    for (int d = 0; d < launched; ++d) {
+    const int top = launched < BUILD_TOP_LEVELS ? launched : BUILD_TOP_LEVELS;
+    hipLaunchKernelGGL(k_build_top<BITS>, dim3(1), dim3(256), 0, s, keys, node_meta, (Split<BITS> *)split, level_start, bsum,
+                       n, counters, top);
+    for (int d = top; d < launched; ++d) {
         const dim3 grid(level_blocks(d, BITS, 4));  // 4 nodes per block while a wave searches for each node
         hipLaunchKernelGGL(k_build_count<BITS>, grid, dim3(256), 0, s, keys, node_meta, (Split<BITS> *)split,
                            level_start, bsum, d);
         hipLaunchKernelGGL(k_build_emit<BITS>, grid, dim3(256), 0, s, node_meta,
                            (const Split<BITS> *)split, level_start, bsum, d);
     }
-    hipLaunchKernelGGL(k_build_tail<BITS>, dim3(1), dim3(256), 0, s, keys, node_meta, level_start, launched);
+    hipLaunchKernelGGL(k_build_tail<BITS>, dim3(1), dim3(256), 0, s, keys, node_meta, level_start, launched, counters,
+                       levels_host);
 }
 
 int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node_meta, void *split, uint32_t *level_start,
-               uint32_t *bsum, unsigned long long *counters, int launched)
+               uint32_t *bsum, unsigned long long *counters, int launched, uint32_t *levels_host)
 {
     if (bits == 3)
-        launch_build<3>(s, keys, n, node_meta, split, level_start, bsum, counters, launched);
+        launch_build<3>(s, keys, n, node_meta, split, level_start, bsum, counters, launched, levels_host);
     else
-        launch_build<2>(s, keys, n, node_meta, split, level_start, bsum, counters, launched);
+        launch_build<2>(s, keys, n, node_meta, split, level_start, bsum, counters, launched, levels_host);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -824,7 +875,8 @@ int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node
 int bh_build(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     b.launched = launched_levels(b.levels_host);
-    return build_tree(s, 2, b.keys[b.sorted], a.n, b.node_meta, b.split, b.level_start, b.bsum, b.counters, b.launched);
+    return build_tree(s, 2, b.keys[b.sorted], a.n, b.node_meta, b.split, b.level_start, b.bsum, b.counters, b.launched,
+                      b.levels_host);
 }
 
 // ------------------------------------------------------------------ 5 centre of mass
@@ -1705,21 +1757,6 @@ __global__ __launch_bounds__(256) void k_tl_emit(const uint32_t *idx, int n, uin
         *tcount = (uint32_t)pos;
 }
 
-__global__ void k_bh_finish_counters(const uint32_t *level_start, unsigned long long *counters,
-                                     uint32_t *levels_host)
-{
-    if (threadIdx.x == 0) {
-        int levels = 0;
-        for (int d = 0; d < BH_MAX_DEPTH; ++d)
-            if (level_start[d + 1] > level_start[d])
-                levels = d + 1;
-        counters[2] = level_start[levels];
-        counters[3] = (unsigned long long)levels;
-        if (levels_host)
-            *levels_host = (uint32_t)levels;  // host-visible: sizes the next steps' launches
-    }
-}
-
 size_t target_list_blocks(int n) { return (size_t)(n + TL_TILE - 1) / TL_TILE + 1; }
 
 int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int t1, uint32_t *tblock, uint32_t *tlist,
@@ -1729,13 +1766,6 @@ int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int
     hipLaunchKernelGGL(k_tl_count, dim3(nblk), dim3(256), 0, s, sorted_idx, n, (uint32_t)t0, (uint32_t)t1, tblock);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, tblock, nblk);
     hipLaunchKernelGGL(k_tl_emit, dim3(nblk), dim3(256), 0, s, sorted_idx, n, (uint32_t)t0, (uint32_t)t1, tblock, tlist, tcount);
-    NB_HIP(hipGetLastError());
-    return NB_OK;
-}
-
-int bh_finish(hipStream_t s, const uint32_t *level_start, unsigned long long *counters, uint32_t *levels_host)
-{
-    hipLaunchKernelGGL(k_bh_finish_counters, dim3(1), dim3(64), 0, s, level_start, counters, levels_host);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -1789,7 +1819,8 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
         else
             hipLaunchKernelGGL((k_bh_force<FM_NOEPS, false>), grid, dim3(256), 0, s, f);
     }
-    return bh_finish(s, b.level_start, b.counters, b.levels_host);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
 }
 
 // ------------------------------------------------------------------ buffers

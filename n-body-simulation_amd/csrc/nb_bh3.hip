@@ -193,7 +193,8 @@ int bh3_sort(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
 int bh3_build(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
 {
     b.launched = launched_levels(b.levels_host);
-    return build_tree(s, 3, b.keys[0], a.n, b.node_meta, b.split, b.level_start, b.bsum, b.counters, b.launched);
+    return build_tree(s, 3, b.keys[0], a.n, b.node_meta, b.split, b.level_start, b.bsum, b.counters, b.launched,
+                      b.levels_host);
 }
 
 // ------------------------------------------------------------------ 5 centre of mass
@@ -869,7 +870,7 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
         ntarget = a.t1 - a.t0;
     }
     if (ntarget <= 0)
-        return bh_finish(s, b.level_start, b.counters, b.levels_host);
+        return NB_OK;
     f.dyn = a.dyn;
     f.radius = a.radius;
     f.pos = a.pos;
@@ -900,7 +901,7 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
             hipLaunchKernelGGL((k_bh3_force<F3_NOEPS, false>), grid, dim3(256), 0, s, f);
     }
     NB_HIP(hipGetLastError());
-    return bh_finish(s, b.level_start, b.counters, b.levels_host);
+    return NB_OK;
 }
 
 // ------------------------------------------------------------------ buffers
