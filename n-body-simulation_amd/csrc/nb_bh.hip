@@ -1084,22 +1084,26 @@ __global__ __launch_bounds__(256) void k_leaf_finish(const uint32_t *chunk_info,
 #pragma unroll
     for (int v = 0; v < NSUM; ++v)
         ps[v] = 0.0;
-    bool open = own;  // the end of the run is not found yet
-#pragma unroll 1
-    for (int it = 1; it <= LEAF_SHORT; ++it) {
-        if (__builtin_amdgcn_ballot_w64(open) == 0ull)
-            break;
-        const int cc = c + it;
+    // the next LEAF_SHORT chunks' words in one round of loads, then the parts that belong to the
+    // run in another (not one chunk after the other: each step would wait for two loads)
+    uint32_t fh[LEAF_SHORT];
+#pragma unroll
+    for (int it = 0; it < LEAF_SHORT; ++it) {
+        const int cc = c + 1 + it;
         // a chunk past the end ends the run like a chunk that starts with a head
-        const uint32_t fh = (open && cc < nchunks) ? (chunk_info[cc] & 0xffu) : 0u;
-        if (open && fh > 0u) {
-            const double *p = leaf_sum + (size_t)STRIDE * ((size_t)cc * 64);
+        fh[it] = (own && cc < nchunks) ? (chunk_info[cc] & 0xffu) : 0u;
+    }
+    bool open = own;  // the end of the run is not found yet
+#pragma unroll
+    for (int it = 0; it < LEAF_SHORT; ++it) {
+        if (open && fh[it] > 0u) {
+            const double *p = leaf_sum + (size_t)STRIDE * ((size_t)(c + 1 + it) * 64);
 #pragma unroll
             for (int v = 0; v < NSUM; ++v)
                 ps[v] += p[v];
             pr = fmax(pr, p[NSUM]);
         }
-        open = open && fh == 64u;
+        open = open && fh[it] == 64u;
     }
     if (own && !open) {
         double *t = leaf_sum + (size_t)STRIDE * ((size_t)c * 64 + (mine >> 8));
