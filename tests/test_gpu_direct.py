@@ -180,15 +180,19 @@ def _hip():
     return C.CDLL("libamdhip64.so")
 
 
-def test_two_rank_partition_equals_single_rank(nb, oracle):
+@pytest.mark.parametrize("cth", [1.0e10, 1.0e9])
+def test_two_rank_partition_equals_single_rank(nb, oracle, cth):
     """Two handles own half the targets each; positions are exchanged through the exchange
     buffers as an all-gather would.  The result must equal the unpartitioned run up to FP32
-    summation order (blocks hold different targets, so their near/far run choices differ)."""
+    summation order (blocks hold different targets, so their near/far run choices differ).
+    With the small cutoff the records carry the coordinates' low parts, which a rank must also
+    refresh for the bodies the other rank advanced."""
     n = 3001
     b = oracle.scenario(0, n, 8)
     hip = _hip()
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    with nb.NBodySim(n, nb.DIRECT) as one, nb.NBodySim(n, nb.DIRECT) as r0, nb.NBodySim(n, nb.DIRECT) as r1:
+    pr = nb.default_params(collision_th=cth)
+    with nb.NBodySim(n, nb.DIRECT, pr) as one, nb.NBodySim(n, nb.DIRECT, pr) as r0, nb.NBodySim(n, nb.DIRECT, pr) as r1:
         for s in (one, r0, r1):
             s.set_bodies(b)
         r0.set_partition(0, 2)
