@@ -181,6 +181,22 @@ def cpu_baseline(nb, bh_n):
     }
 
 
+def launch_ranks(n):
+    """Runs this script as n ranks of torch.distributed.run on this node; returns its exit code.
+    The ranks' output (rank 0's JSON line) passes straight through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,7 +208,14 @@ def main():
     ap.add_argument("--no-direct", action="store_true", help="skip the direct-sum half of the metric")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher: start one rank per GPU ourselves.  Nothing in this process
+        # has touched the GPU yet, and the ranks are fresh child processes.
+        sys.exit(launch_ranks(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():

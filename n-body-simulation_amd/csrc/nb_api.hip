@@ -41,6 +41,7 @@ struct nb_sim {
     bool own_stream = false;
     bool have_bodies = false;
     bool first_kick = true;  // leapfrog: the next step is the first since the bodies were set
+    bool stepped = false;    // a step was taken since the bodies were set
     long steps_in_order = 0; // steps since the exchange order was last derived from the positions
 
     Units units{};
@@ -65,6 +66,7 @@ struct nb_sim {
 
     // direct sum
     double2 *part = nullptr;
+    size_t part_cap = 0;  // records allocated in part
     int jsplit = 1;
     uint8_t *ds_meta = nullptr;  // per-run bounding boxes (direct_meta_bytes)
 
@@ -218,6 +220,7 @@ int step_local(nb_sim *s, int do_integrate)
 int step_finish(nb_sim *s)
 {
     s->first_kick = false;
+    s->stepped = true;
     if (s->alg == NB_ALG_DIRECT) {
         // records of the bodies other ranks advanced come from the gathered positions
         if (s->world > 1) {
@@ -322,7 +325,8 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
         }
         chk(dev_alloc(s->rad_s, s->cap));
         s->jsplit = direct_choose_jsplit(n, n);
-        chk(dev_alloc(s->part, (size_t)s->jsplit * n));
+        s->part_cap = (size_t)s->jsplit * n;
+        chk(dev_alloc(s->part, s->part_cap));
         chk(dev_alloc(s->ds_meta, direct_meta_bytes(n)));
     } else {
         chk(bh_alloc(s->bh, n));
@@ -410,6 +414,7 @@ int nb_set_bodies(nb_sim *s, const nb_body *b, int n)
     s->have_bodies = true;
     s->mid_step = false;
     s->first_kick = true;
+    s->stepped = false;
     return NB_OK;
 }
 
@@ -552,8 +557,14 @@ int nb_read_bodies(nb_sim *s, nb_body *out)
     // leapfrog keeps velocities half a step behind the positions; bring them level with the
     // force at the current positions
     const bool half_step = s->p.integrator == NB_INT_LEAPFROG && !s->first_kick && !s->mid_step;
-    if (half_step)
-        NB_TRY(step_local(s, 0));
+    if (half_step) {
+        // this force evaluation is not a step: keep it out of the per-stage timing
+        const int timing = s->timer.on;
+        s->timer.on = 0;
+        const int rc = step_local(s, 0);
+        s->timer.on = timing;
+        NB_TRY(rc);
+    }
     NB_HIP(hipStreamSynchronize(s->stream));
     NB_HIP(hipMemcpy(pos.data(), s->pos, sizeof(double2) * n, hipMemcpyDeviceToHost));
     NB_HIP(hipMemcpy(vel.data(), s->vel, sizeof(double2) * n, hipMemcpyDeviceToHost));
@@ -624,6 +635,10 @@ int nb_set_partition(nb_sim *s, int rank, int world)
         return fail(NB_ERR_ARG, "nb_set_partition: need 0 <= rank < world <= 64");
     if (!s->have_bodies)
         return fail(NB_ERR_STATE, "nb_set_partition: set the bodies first");
+    if (s->mid_step)
+        return fail(NB_ERR_STATE, "nb_set_partition: a split step is in flight");
+    if (s->stepped)
+        return fail(NB_ERR_STATE, "nb_set_partition: the simulation was stepped already; set the bodies again first");
     s->rank = rank;
     s->world = world;
     s->chunk = ((size_t)s->n + world - 1) / world;
@@ -632,10 +647,13 @@ int nb_set_partition(nb_sim *s, int rank, int world)
     if (s->alg == NB_ALG_DIRECT) {
         // fewer targets per rank: split the sources further so the chip stays full
         const int js = direct_choose_jsplit(s->n, s->t1 - s->t0);
-        if ((size_t)js * (size_t)(s->t1 - s->t0) > (size_t)s->jsplit * (size_t)s->n) {
+        const size_t need = (size_t)js * (size_t)(s->t1 - s->t0);
+        if (need > s->part_cap) {
             (void)hipFree(s->part);
             s->part = nullptr;
-            NB_TRY(dev_alloc(s->part, (size_t)js * (size_t)(s->t1 - s->t0)));
+            s->part_cap = 0;
+            NB_TRY(dev_alloc(s->part, need));
+            s->part_cap = need;
         }
         s->jsplit = js;
     }

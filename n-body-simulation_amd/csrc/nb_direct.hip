@@ -24,8 +24,6 @@
 //
 // Per interaction (2-D), far run: 2 sub, 2 fma, 1 rsq, 2-3 mul, 2 fma; near run: + add, fma,
 // cmp, select and the tie test.  Bound: FP32 vector ALU (no MFMA: no dense contraction here).
-#include <cstdlib>
-
 #include "nb_common.h"
 
 namespace nb {
@@ -60,11 +58,13 @@ constexpr int DS_FLUSH = NB_DS_FLUSH;   // pairs between FP32 -> FP64 folds
 // A float cutoff comparison closer than this fraction is repeated in FP64: the float distance
 // carries the coordinates' rounding (2^-24 of the domain each), a few 1e-6 of the cutoff.
 constexpr float DS_BAND = 4.0e-5f;
-// safety factor on the squared box gap that lets a run skip the cutoff test
+// safety factor and absolute margin (internal units: coordinates lie in [-8, 8), their float
+// rounding is up to 4.8e-7) on the box gap that lets a run skip the cutoff test
 #ifndef NB_DS_GAP_SLACK
-#define NB_DS_GAP_SLACK 1.001f
+#define NB_DS_GAP_SLACK 1.0005f
 #endif
 constexpr float DS_GAP_SLACK = NB_DS_GAP_SLACK;
+constexpr float DS_GAP_ABS = 4.0e-6f;
 
 // Bounding box of a run of DS_SUB sources, its largest cutoff radius and its common mass.
 struct SubMeta {
@@ -466,9 +466,13 @@ __global__ __launch_bounds__(DS_BLOCK) NB_DS_OCC void k_direct(DirectLaunch a)
             const SubMeta m = a.meta[j0 / DS_SUB];
             const float gx = fmaxf(fmaxf(m.x0 - bx1, bx0 - m.x1), 0.f);
             const float gy = fmaxf(fmaxf(m.y0 - by1, by0 - m.y1), 0.f);
-            const float lim = rimax + m.wmax;
+            // The boxes are those of the float records; the FP64 positions the reference decides on
+            // differ from them by up to 2^-21 units per coordinate, so the gap needs an absolute
+            // margin beside the relative one (with a tiny cutoff the relative one alone is smaller
+            // than that rounding).
+            const float lim = (rimax + m.wmax) * DS_GAP_SLACK + DS_GAP_ABS;
             // far: no pair of the two boxes can be inside the cutoff (a NaN anywhere means near)
-            const bool far = __builtin_fmaf(gx, gx, gy * gy) > lim * lim * DS_GAP_SLACK;
+            const bool far = __builtin_fmaf(gx, gx, gy * gy) > lim * lim;
             const bool uni = m.mu == m.mu;
             const float4 *rec = cur + sub * DS_SUB;
             if (far) {
@@ -568,6 +572,10 @@ int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const doubl
 }
 
 constexpr int DS_TPT = NB_DS_TPT;
+#ifndef NB_DS_MAXSPLIT
+#define NB_DS_MAXSPLIT 64
+#endif
+constexpr int DS_MAX_SPLIT = NB_DS_MAXSPLIT;  // most slices the source range is cut into
 
 size_t direct_meta_bytes(int n) { return sizeof(SubMeta) * (size_t)((n + DS_SUB - 1) / DS_SUB); }
 
@@ -577,16 +585,13 @@ int direct_choose_jsplit(int n, int nt)
     // Splitting the source range across blockIdx.y makes blocks many and short: ~65k blocks
     // keep the 256 CUs within ~1 % of each other (measured: 1 split 4.4, 16 splits 5.0
     // T interactions/s at N = 1M), and give small N enough waves to fill the chip at all.
+    if (nt <= 0)
+        return 1;  // a rank without targets launches nothing
     const int tb = (nt + DS_BLOCK * DS_TPT - 1) / (DS_BLOCK * DS_TPT);
     const int ntiles = (n + DS_SUB - 1) / DS_SUB;  // a split is a whole number of runs
-    if (const char *e = getenv("NB_DS_JSPLIT"))  // tuning override
-        return atoi(e) < 1 ? 1 : (atoi(e) > ntiles ? ntiles : atoi(e));
     int want = (65536 + tb - 1) / tb;
-    if (const char *e = getenv("NB_DS_MAXSPLIT")) {
-        if (want > atoi(e))
-            want = atoi(e);
-    } else if (want > 64)
-        want = 64;
+    if (want > DS_MAX_SPLIT)
+        want = DS_MAX_SPLIT;
     // partial sums: 16 B per target and split; stay below 1 GiB
     while (want > 1 && (size_t)want * (size_t)nt * sizeof(double2) > ((size_t)1 << 30))
         --want;

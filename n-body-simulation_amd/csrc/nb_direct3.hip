@@ -26,7 +26,8 @@ constexpr int DS3_TILE = 1024;
 constexpr int DS3_SUB = 256;
 constexpr int DS3_FLUSH = 32;
 constexpr float DS3_BAND = 4.0e-5f;      // see DS_BAND in nb_direct.hip
-constexpr float DS3_GAP_SLACK = 1.001f;
+constexpr float DS3_GAP_SLACK = 1.0005f;  // relative margin on the box gap of a far run ...
+constexpr float DS3_GAP_ABS = 4.0e-6f;     // ... and the absolute one (float rounding of the coordinates, internal units)
 
 struct SubMeta3 {
     float x0, x1, y0, y1, z0, z1;
@@ -403,9 +404,9 @@ __global__ __launch_bounds__(DS3_BLOCK) void k_direct3(Direct3Launch a)
             const float gx = fmaxf(fmaxf(m.x0 - hi[0], lo[0] - m.x1), 0.f);
             const float gy = fmaxf(fmaxf(m.y0 - hi[1], lo[1] - m.y1), 0.f);
             const float gz = fmaxf(fmaxf(m.z0 - hi[2], lo[2] - m.z1), 0.f);
-            const float lim = rimax + m.wmax;
+            const float lim = (rimax + m.wmax) * DS3_GAP_SLACK + DS3_GAP_ABS;
             // far: no pair of the two boxes can be inside the cutoff (a NaN anywhere means near)
-            const bool far = __builtin_fmaf(gx, gx, __builtin_fmaf(gy, gy, gz * gz)) > lim * lim * DS3_GAP_SLACK;
+            const bool far = __builtin_fmaf(gx, gx, __builtin_fmaf(gy, gy, gz * gz)) > lim * lim;
             const bool uni = m.mu == m.mu;
             const float4 *rec = cur + sub * DS3_SUB;
             const float *wc = wcur + sub * DS3_SUB;
@@ -497,6 +498,8 @@ int pack_posm3(hipStream_t s, const double *pos, const double *mass, const doubl
 int direct3_choose_jsplit(int n, int nt)
 {
     // many short blocks keep the 256 CUs level (see direct_choose_jsplit)
+    if (nt <= 0)
+        return 1;  // a rank without targets launches nothing
     const int tb = (nt + DS3_BLOCK * DS3_TPT - 1) / (DS3_BLOCK * DS3_TPT);
     const int ntiles = (n + DS3_TILE - 1) / DS3_TILE;
     int want = (65536 + tb - 1) / tb;

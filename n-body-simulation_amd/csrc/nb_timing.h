@@ -38,7 +38,7 @@ struct StageTimer {
 
     void mark(hipStream_t stream, int k)
     {
-        if (on)
+        if (on && used < RING)
             (void)hipEventRecord(ev[used][k], stream);
     }
 
@@ -48,9 +48,11 @@ struct StageTimer {
     {
         if (used == 0)
             return NB_OK;
+        const int pending = used;
+        used = 0;  // also when the wait fails: mark() must never index past the ring
         NB_HIP(hipStreamSynchronize(stream));
         const int last = direct ? 1 : 6;
-        for (int e = 0; e < used; ++e) {
+        for (int e = 0; e < pending; ++e) {
             for (int k = 0; k < last; ++k) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, ev[e][k], ev[e][k + 1]) == hipSuccess)
@@ -58,7 +60,6 @@ struct StageTimer {
             }
             steps += 1;
         }
-        used = 0;
         return NB_OK;
     }
 

@@ -25,6 +25,13 @@
 #define ORC_EARTH_MASS 5.974e24
 #define ORC_EARTH_DIA 12756
 
+/* Threads the per-target loops use (the reference itself is single-threaded: 1 is its timing;
+ * more threads only give the "all host cores" figure of the benchmark's CPU baseline).  The
+ * results do not depend on it: every target's sum is formed by one thread in the same order. */
+static int g_threads = 1;
+
+void orc_set_threads(int threads) { g_threads = threads < 1 ? 1 : threads; }
+
 void orc_default_params(orc_params *p)
 {
     p->gravity = 6.67E-11;     /* constants.h:25 */
@@ -147,12 +154,14 @@ static void direct_one(const orc_params *p, int n, const orc_body *b, int i, dou
 
 void orc_direct_accel(const orc_params *p, int n, const orc_body *b, int t0, int t1, double *acc)
 {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int i = t0; i < t1; ++i)
         direct_one(p, n, b, i, &acc[2 * (i - t0)], &acc[2 * (i - t0) + 1]);
 }
 
 void orc_direct_accel_list(const orc_params *p, int n, const orc_body *b, int nt, const int *targets, double *acc)
 {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int k = 0; k < nt; ++k)
         direct_one(p, n, b, targets[k], &acc[2 * k], &acc[2 * k + 1]);
 }
@@ -377,42 +386,74 @@ static void qt_force(trav *tv, int ni, int body)
     qt_force(tv, q->child[3], body);
 }
 
-int orc_bh_accel(const orc_params *p, int n, const orc_body *b, double *acc, double *stats)
+/* Bounding box, tree and centres of mass of one step (barnesHut.cpp:136-140).  order (may be
+ * NULL) gives the sequence in which the bodies are inserted: the tree of a one-body-per-leaf
+ * quadtree does not depend on it, only the time the insertions take does. */
+static int qt_build(qtree *t, const orc_params *p, int n, const orc_body *b, const int *order)
 {
     double box[4];
     orc_bh_bbox(p, n, b, box);
-    qtree t;
-    memset(&t, 0, sizeof(t));
-    int root = qt_new(&t, box[0], box[1], box[2], box[3]);
+    memset(t, 0, sizeof(*t));
+    int root = qt_new(t, box[0], box[1], box[2], box[3]);
     for (int i = 0; i < n; ++i)
-        qt_insert(&t, root, b, i, 0); /* constructQuadTree, barnesHut.cpp:37-43 */
-    if (t.failed) {
-        free(t.nd);
+        qt_insert(t, root, b, order ? order[i] : i, 0); /* constructQuadTree, barnesHut.cpp:37-43 */
+    if (t->failed) {
+        free(t->nd);
+        t->nd = NULL;
         return -1;
     }
-    qt_center_mass(&t, root, b);
-    trav tv;
-    tv.p = p;
-    tv.b = b;
-    tv.t = &t;
-    tv.eps2 = p->eps * p->eps;
-    tv.visits = tv.accepted = 0;
-    for (int i = 0; i < n; ++i) {
-        /* calculateAcceleration, barnesHut.cpp:96-106 */
+    qt_center_mass(t, root, b);
+    return root;
+}
+
+/* calculateAcceleration, barnesHut.cpp:96-106, for the bodies targets[0..nt) (NULL: body k). */
+static void qt_accel_targets(const qtree *t, int root, const orc_params *p, const orc_body *b, int nt, const int *targets,
+                             double *acc, double *visits, double *accepted)
+{
+    double nv = 0.0, na = 0.0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : nv, na) num_threads(g_threads) if (g_threads > 1)
+    for (int k = 0; k < nt; ++k) {
+        const int i = targets ? targets[k] : k;
         if (b[i].is_dynamic) {
+            trav tv;
+            tv.p = p;
+            tv.b = b;
+            tv.t = t;
+            tv.eps2 = p->eps * p->eps;
+            tv.visits = tv.accepted = 0;
             tv.ax = 0.0;
             tv.ay = 0.0;
             qt_force(&tv, root, i);
-            acc[2 * i] = tv.ax;
-            acc[2 * i + 1] = tv.ay;
+            acc[2 * k] = tv.ax;
+            acc[2 * k + 1] = tv.ay;
+            nv += tv.visits;
+            na += tv.accepted;
         } else {
-            acc[2 * i] = b[i].ax;
-            acc[2 * i + 1] = b[i].ay;
+            acc[2 * k] = b[i].ax;
+            acc[2 * k + 1] = b[i].ay;
         }
     }
+    *visits = nv;
+    *accepted = na;
+}
+
+int orc_bh_accel(const orc_params *p, int n, const orc_body *b, double *acc, double *stats)
+{
+    return orc_bh_accel_list(p, n, b, NULL, n, NULL, acc, stats);
+}
+
+int orc_bh_accel_list(const orc_params *p, int n, const orc_body *b, const int *order, int nt, const int *targets,
+                      double *acc, double *stats)
+{
+    qtree t;
+    const int root = qt_build(&t, p, n, b, order);
+    if (root < 0)
+        return -1;
+    double visits, accepted;
+    qt_accel_targets(&t, root, p, b, nt, targets, acc, &visits, &accepted);
     if (stats) {
-        stats[0] = tv.visits;
-        stats[1] = tv.accepted;
+        stats[0] = visits;
+        stats[1] = accepted;
         stats[2] = t.max_depth;
         stats[3] = t.count;
     }

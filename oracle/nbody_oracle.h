@@ -33,6 +33,10 @@ typedef struct orc_params {
 
 void orc_default_params(orc_params *p);
 
+/* Threads for the per-target loops of the *_accel functions (default 1, the reference's own
+ * single thread).  Results are independent of it. */
+void orc_set_threads(int threads);
+
 /* Scenarios 0 spiral, 1 random, 2 collision, 3 solar (GPU-BH numbering). */
 int orc_init_scenario(int sim, int n, unsigned seed, orc_body *out);
 
@@ -49,6 +53,12 @@ void orc_bh_bbox(const orc_params *p, int n, const orc_body *b, double *box);
  * two bodies coincide (the reference recurses without end there). stats may be NULL:
  * [0] node visits, [1] accepted cells + leaf bodies, [2] max depth, [3] tree nodes. */
 int orc_bh_accel(const orc_params *p, int n, const orc_body *b, double *acc, double *stats);
+/* The same for the bodies targets[0..nt) only (acc = 2 doubles per listed target): the tree of
+ * all n bodies is built once and walked for those.  order, when not NULL, is the sequence in which
+ * the bodies are inserted (a permutation of 0..n-1; the resulting tree does not depend on it, but
+ * inserting in a spatially sorted order is several times faster at millions of bodies). */
+int orc_bh_accel_list(const orc_params *p, int n, const orc_body *b, const int *order, int nt, const int *targets,
+                      double *acc, double *stats);
 /* nsteps of BarnesHut::update on b in place; returns 0 or -1 as above. */
 int orc_bh_step(const orc_params *p, int n, orc_body *b, int nsteps);
 

@@ -82,6 +82,10 @@ class Oracle:
         L.orc_bh_accel.restype = C.c_int
         L.orc_bh_step.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int]
         L.orc_bh_step.restype = C.c_int
+        L.orc_bh_accel_list.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+        L.orc_bh_accel_list.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]
         L.orc_morton_keys.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bh_gpu_bbox.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p]
         L.orc_bh_gpu_accel.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -144,6 +148,29 @@ class Oracle:
         acc = np.zeros((len(b), 2))
         stats = np.zeros(4)
         rc = self.lib.orc_bh_accel(C.byref(p), len(b), _ptr(b), _ptr(acc), _ptr(stats))
+        if rc != 0:
+            raise ValueError("coincident bodies")
+        return (acc, stats) if with_stats else acc
+
+    def set_threads(self, threads):
+        """Threads of the per-target loops (1 = the reference's single thread)."""
+        self.lib.orc_set_threads(int(threads))
+
+    def bh_accel_list(self, b, targets, p=None, sorted_insert=True, with_stats=False):
+        """Barnes-Hut accelerations of the listed bodies only, from the tree of all bodies.
+        sorted_insert: insert the bodies in the order of their quadrant paths (same tree, built
+        several times faster at millions of bodies)."""
+        p = p or self.params()
+        t = np.ascontiguousarray(targets, dtype=np.int32)
+        order = None
+        if sorted_insert:
+            keys = self.morton_keys(b, self.bh_bbox(b, p))
+            order = np.ascontiguousarray(np.argsort(keys, kind="stable"), dtype=np.int32)
+            del keys
+        acc = np.zeros((len(t), 2))
+        stats = np.zeros(4)
+        rc = self.lib.orc_bh_accel_list(C.byref(p), len(b), _ptr(b), _ptr(order) if order is not None else None,
+                                        len(t), _ptr(t), _ptr(acc), _ptr(stats))
         if rc != 0:
             raise ValueError("coincident bodies")
         return (acc, stats) if with_stats else acc

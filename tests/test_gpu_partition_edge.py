@@ -1,0 +1,96 @@
+"""Partitions in which some ranks own no body at all.
+
+chunk = ceil(n / world), so a rank's slice [rank * chunk, (rank + 1) * chunk) is empty whenever
+(world - 1) * chunk >= n: the reference's 5-body solar system on 4 ranks gives slices of
+2, 2, 1 and 0 bodies.  Every handle, the empty one included, must step without error and the
+ranks together must reproduce the unpartitioned run (bar: positions within 1e-9 of the system's
+extent after 5 steps; the runs differ only by FP32 summation order).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return hip
+
+
+def step_ranks_together(hip, ranks, n):
+    """One step of `ranks` (handles partitioned 0..world-1 on one GPU) with the all-gather of
+    positions done by device-to-device copies between their exchange buffers."""
+    world = len(ranks)
+    for s in ranks:
+        s.step_local()
+    for s in ranks:
+        s.sync()
+    bufs = [s.exchange_buffer() for s in ranks]
+    chunk, rb = bufs[0][1], bufs[0][2]
+    for src in range(world):
+        lo, hi = min(n, src * chunk), min(n, (src + 1) * chunk)
+        if hi <= lo:
+            continue
+        for dst in range(world):
+            if dst != src:
+                assert hip.hipMemcpy(bufs[dst][0] + lo * rb, bufs[src][0] + lo * rb, (hi - lo) * rb, 3) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    for s in ranks:
+        s.step_finish()
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+@pytest.mark.parametrize("alg", ["direct", "bh"])
+@pytest.mark.parametrize("n,world", [(5, 4), (49, 8)])
+def test_ranks_with_an_empty_slice_step_like_the_others(nb, oracle, dims, alg, n, world):
+    algc = nb.DIRECT if alg == "direct" else nb.BARNES_HUT
+    if dims == 2:
+        b = nb.init_scenario(nb.SOLAR if n == 5 else nb.SPIRAL, n, 3)
+        make = lambda: nb.NBodySim(n, algc)  # noqa: E731
+    else:
+        b = nb.init_scenario3(nb.SOLAR if n == 5 else nb.SPIRAL, n, 3, 1.0e10)
+        make = lambda: nb.NBodySim3(n, algc)  # noqa: E731
+    chunk = (n + world - 1) // world
+    assert (world - 1) * chunk >= n, "the case must hold a rank without bodies"
+    hip = _hip()
+    one = make()
+    ranks = [make() for _ in range(world)]
+    try:
+        one.set_bodies(b)
+        for r, s in enumerate(ranks):
+            s.set_bodies(b)
+            s.set_partition(r, world)
+        for _ in range(5):
+            one.update()
+            step_ranks_together(hip, ranks, n)
+        ref = one.read_bodies()
+        outs = [s.read_bodies() for s in ranks]
+        order = ranks[0].order()
+    finally:
+        one.close()
+        for s in ranks:
+            s.close()
+    extent = np.abs(ref["pos"]).max()
+    for o in outs:
+        assert np.array_equal(o["pos"], outs[0]["pos"])
+        assert np.linalg.norm(o["pos"] - ref["pos"], axis=1).max() <= 1e-9 * extent
+    # every rank keeps the velocities of its own slots up to date
+    for r, o in enumerate(outs):
+        own = order[min(n, r * chunk):min(n, (r + 1) * chunk)]
+        assert np.allclose(o["vel"][own], ref["vel"][own], rtol=1e-6, atol=1e-6)
+
+
+def test_partition_is_refused_once_stepped(nb):
+    with nb.NBodySim(64, nb.DIRECT) as sim:
+        sim.setup(nb.RANDOM, 1)
+        sim.update()
+        with pytest.raises(nb.NBodyError, match="stepped already"):
+            sim.set_partition(0, 2)
+        sim.setup(nb.RANDOM, 1)
+        sim.set_partition(0, 2)
+        sim.step_local()
+        with pytest.raises(nb.NBodyError, match="in flight"):
+            sim.set_partition(1, 2)
