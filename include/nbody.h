@@ -208,6 +208,28 @@ int nb_refresh_order(nb_sim *sim);
  * the pairs the force law does not skip (NaN when n > 131072: it is an O(n^2) sum). */
 int nb_diagnostics(nb_sim *sim, double *out, int count);
 
+/* ---- a force evaluation that allocates nothing ----
+ *
+ * No counterpart in the reference.  For callers that cannot allocate device memory or touch host
+ * buffers where they call: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  It is nb_compute_accel with device arrays for input and output: the Barnes-Hut
+ * accelerations the bodies of `sim` (their masses, radii, dynamic flags and parameters) have at the
+ * positions pos_xy -- n records {x, y} in device memory, in the order the bodies were given to
+ * nb_set_bodies -- written to acc_xy (device memory, n records {ax, ay}, same order; a static body
+ * gets the acceleration the handle holds for it, as nb_read_bodies would return).  The handle's own
+ * state (positions, velocities, step count) is neither read nor changed.
+ *
+ * Everything in between (permuted positions, keys, sort buffers, tree, centres of mass, traversal
+ * records) lives in one static device array of 40 MiB that every GPU the library runs on holds
+ * until the process ends, so the call makes no hipMalloc/hipFree and only enqueues kernels on
+ * hip_stream (a hipStream_t; NULL: the handle's stream).  n above NB_STATIC_MAX_BODIES is refused
+ * with NB_ERR_OVERFLOW.  All calls on one GPU share the array: calls that overlap in time on one
+ * GPU (two streams, two threads, two handles) race; calls on one stream do not.  `sim` must be a
+ * Barnes-Hut handle created on the current device (nb_create looks the array's address up, once
+ * per device, so this call does not have to). */
+#define NB_STATIC_MAX_BODIES 131072
+int nb_compute_accel_static(nb_sim *sim, const double *pos_xy, double *acc_xy, void *hip_stream);
+
 /* ==== three dimensions ====
  *
  * The reference is two-dimensional (struct Vector holds x and y, src/cpu/vector.h); its authors

@@ -52,12 +52,14 @@ DBG_BBOX, DBG_KEYS, DBG_SORTED_KEYS, DBG_SORTED_IDX = 0, 1, 2, 3
 DBG_NODE_RANGE, DBG_NODE_CHILD, DBG_NODE_COM, DBG_LEVEL_START, DBG_ORDER, DBG_COUNTERS = 4, 5, 6, 7, 8, 9
 DBG_KEY_LEVELS = 10
 
+STATIC_MAX_BODIES = 131072  # NB_STATIC_MAX_BODIES of include/nbody.h
+
 # Every symbol include/nbody.h declares.
 ABI_SYMBOLS = [
     "nb_default_params", "nb_init_scenario", "nb_create", "nb_destroy", "nb_setup", "nb_set_bodies",
     "nb_step", "nb_compute_accel", "nb_read_bodies", "nb_sync", "nb_set_stream", "nb_set_partition",
     "nb_exchange_buffer", "nb_step_local", "nb_step_finish", "nb_debug_read", "nb_set_stage_timing",
-    "nb_stage_ms", "nb_diagnostics", "nb_refresh_order", "nb_last_error", "nb_version",
+    "nb_stage_ms", "nb_diagnostics", "nb_refresh_order", "nb_compute_accel_static", "nb_last_error", "nb_version",
     "nb3_init_scenario", "nb3_create", "nb3_destroy", "nb3_setup", "nb3_set_bodies", "nb3_step",
     "nb3_compute_accel", "nb3_read_bodies", "nb3_sync", "nb3_debug_read", "nb3_set_stage_timing", "nb3_stage_ms",
     "nb3_diagnostics", "nb3_set_stream", "nb3_set_partition", "nb3_exchange_buffer", "nb3_step_local", "nb3_step_finish",
@@ -118,6 +120,7 @@ def load_library(path=None):
     lib.nb_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]
     lib.nb_diagnostics.argtypes = [vp, C.POINTER(C.c_double), i]
     lib.nb_refresh_order.argtypes = [vp]
+    lib.nb_compute_accel_static.argtypes = [vp, vp, vp, vp]
     lib.nb3_init_scenario.argtypes = [i, i, u, C.c_double, vp]
     lib.nb3_create.argtypes = [C.POINTER(Params), i, i, C.POINTER(vp)]
     lib.nb3_destroy.argtypes = [vp]
@@ -246,6 +249,11 @@ class NBodySim:
     def refresh_order(self):
         """Re-sorts the device state by the bodies' current positions (see nb_refresh_order)."""
         _check(self._lib.nb_refresh_order(self._h))
+
+    def compute_accel_static(self, pos_ptr, acc_ptr, stream=None):
+        """nb_compute_accel_static: accelerations at the positions in device memory at pos_ptr
+        (n x 2 doubles, caller order) into device memory at acc_ptr; allocates nothing."""
+        _check(self._lib.nb_compute_accel_static(self._h, C.c_void_p(pos_ptr), C.c_void_p(acc_ptr), C.c_void_p(stream)))
 
     def diagnostics(self):
         """Conserved quantities of the current state (FP64); potential is NaN above 131072 bodies."""

@@ -12,9 +12,7 @@
 #include <numeric>
 #include <vector>
 
-#include "nb_bh.h"
-#include "nb_common.h"
-#include "nb_timing.h"
+#include "nb_sim.h"
 
 namespace nb {
 
@@ -32,50 +30,47 @@ int fail(int status, const std::string &msg)
 
 using namespace nb;
 
-struct nb_sim {
-    nb_params p;
-    int n = 0;
-    int alg = 0;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    bool have_bodies = false;
-    bool first_kick = true;  // leapfrog: the next step is the first since the bodies were set
-    bool stepped = false;    // a step was taken since the bodies were set
-    long steps_in_order = 0; // steps since the exchange order was last derived from the positions
+namespace nb {
 
-    Units units{};
-    ForceConsts fc{};
+IntegrateArgs integrate_args(const nb_sim *s, int do_integrate)
+{
+    IntegrateArgs ia;
+    ia.acc_factor = s->units.acc_factor;
+    ia.dt = s->p.dt;
+    ia.dt_kick = (s->p.integrator == NB_INT_LEAPFROG && s->first_kick) ? 0.5 * s->p.dt : s->p.dt;
+    ia.inv_len_unit = 1.0 / s->units.len_unit;
+    for (int d = 0; d < 3; ++d)
+        ia.origin[d] = s->units.origin[d];
+    ia.do_integrate = do_integrate;
+    ia.static_fixed = (s->alg == NB_ALG_BARNES_HUT && s->p.bucket_depth > 0) ? 1 : 0;
+    return ia;
+}
 
-    // state in exchange order; pos has room for world*chunk records
-    size_t cap = 0;
-    double2 *pos = nullptr, *vel = nullptr, *acc = nullptr;
-    double2 *pos2 = nullptr;  // direct sum: the other FP64 position buffer (pos is the current one)
-    double *mass = nullptr, *radius = nullptr;
-    uint8_t *dyn = nullptr;
-    float4 *posm[2] = {nullptr, nullptr};
-    float *rad_s = nullptr;
-    int cur = 0;
-    std::vector<uint32_t> order;  // caller index of the body in each exchange-order slot
+BhStepArgs bh_args(nb_sim *s, int do_integrate)
+{
+    BhStepArgs a;
+    a.pos = s->pos;
+    a.mass = s->mass;
+    a.radius = s->radius;
+    a.dyn = s->dyn;
+    a.vel = s->vel;
+    a.acc = s->acc;
+    a.pos_out = s->pos;
+    a.n = s->n;
+    a.t0 = s->t0;
+    a.t1 = s->t1;
+    a.units = s->units;
+    a.fc = s->fc;
+    a.ia = integrate_args(s, do_integrate);
+    a.theta = s->p.theta;
+    a.bbox_margin = s->p.bbox_margin;
+    a.collision_th = s->p.collision_th;
+    a.bucket_depth = s->p.bucket_depth;
+    a.collect_stats = s->collect_stats;
+    return a;
+}
 
-    // partition
-    int rank = 0, world = 1;
-    size_t chunk = 0;
-    int t0 = 0, t1 = 0;
-    bool mid_step = false;
-
-    // direct sum
-    double2 *part = nullptr;
-    size_t part_cap = 0;  // records allocated in part
-    int jsplit = 1;
-    uint8_t *ds_meta = nullptr;  // per-run bounding boxes (direct_meta_bytes)
-
-    // Barnes-Hut
-    BhBuffers bh;
-    int collect_stats = 0;
-
-    StageTimer timer;
-};
+}  // namespace nb
 
 namespace {
 
@@ -150,44 +145,6 @@ void exchange_order(const nb_body *b, int n, std::vector<uint32_t> &order)
         order[i] = (uint32_t)(kv[i] & 0xffffffffu);
 }
 
-IntegrateArgs integrate_args(const nb_sim *s, int do_integrate)
-{
-    IntegrateArgs ia;
-    ia.acc_factor = s->units.acc_factor;
-    ia.dt = s->p.dt;
-    ia.dt_kick = (s->p.integrator == NB_INT_LEAPFROG && s->first_kick) ? 0.5 * s->p.dt : s->p.dt;
-    ia.inv_len_unit = 1.0 / s->units.len_unit;
-    for (int d = 0; d < 3; ++d)
-        ia.origin[d] = s->units.origin[d];
-    ia.do_integrate = do_integrate;
-    ia.static_fixed = (s->alg == NB_ALG_BARNES_HUT && s->p.bucket_depth > 0) ? 1 : 0;
-    return ia;
-}
-
-BhStepArgs bh_args(nb_sim *s, int do_integrate)
-{
-    BhStepArgs a;
-    a.pos = s->pos;
-    a.mass = s->mass;
-    a.radius = s->radius;
-    a.dyn = s->dyn;
-    a.vel = s->vel;
-    a.acc = s->acc;
-    a.pos_out = s->pos;
-    a.n = s->n;
-    a.t0 = s->t0;
-    a.t1 = s->t1;
-    a.units = s->units;
-    a.fc = s->fc;
-    a.ia = integrate_args(s, do_integrate);
-    a.theta = s->p.theta;
-    a.bbox_margin = s->p.bbox_margin;
-    a.collision_th = s->p.collision_th;
-    a.bucket_depth = s->p.bucket_depth;
-    a.collect_stats = s->collect_stats;
-    return a;
-}
-
 void mark(nb_sim *s, int k) { s->timer.mark(s->stream, k); }
 
 int step_local(nb_sim *s, int do_integrate)
@@ -246,6 +203,7 @@ void release(nb_sim *s)
     (void)hipFree(s->mass);
     (void)hipFree(s->radius);
     (void)hipFree(s->dyn);
+    (void)hipFree(s->order_d);
     (void)hipFree(s->posm[0]);
     (void)hipFree(s->posm[1]);
     (void)hipFree(s->rad_s);
@@ -316,6 +274,7 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
     chk(dev_alloc(s->mass, s->cap));
     chk(dev_alloc(s->radius, s->cap));
     chk(dev_alloc(s->dyn, s->cap));
+    chk(dev_alloc(s->order_d, s->cap));
     if (alg == NB_ALG_DIRECT) {
         chk(dev_alloc(s->pos2, s->cap));
         for (int k = 0; k < 2; ++k) {
@@ -333,6 +292,8 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
     }
     if (rc == NB_OK)
         chk(s->timer.create());
+    if (rc == NB_OK)
+        chk(static_scratch_init(s->device));
     if (rc != NB_OK) {
         release(s);
         delete s;
@@ -388,6 +349,7 @@ static int load_bodies(nb_sim *s, const nb_body *b, int n)
     NB_HIP(hipMemcpy(s->mass, mass.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(s->radius, radius.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(s->dyn, dyn.data(), n, hipMemcpyHostToDevice));
+    NB_HIP(hipMemcpy(s->order_d, s->order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
     if (s->alg == NB_ALG_DIRECT) {
         s->cur = 0;
         NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, n, 0, n, s->units, s->p.collision_th, s->posm[0], s->rad_s));

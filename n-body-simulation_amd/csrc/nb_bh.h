@@ -17,6 +17,7 @@ constexpr int BH_MAX_DEPTH = 34;   // tree levels the build loops over (31 cell 
 constexpr int BH_SCAN_BLOCKS = 1024;
 
 struct BhBuffers {
+    bool owned = false;  // the arrays were hipMalloc'ed by bh_alloc (bh_free releases them)
     int n = 0;
     size_t node_cap = 0;
     double *box = nullptr;        // tl.x, tl.y, br.x, br.y (float-rounded values held in doubles)
@@ -53,6 +54,9 @@ struct BhBuffers {
 
 int bh_alloc(BhBuffers &b, int n);
 void bh_free(BhBuffers &b);
+// The buffers laid out inside a caller-provided device arena of `bytes` bytes, nothing allocated;
+// with base == nullptr only *used (bytes needed for n bodies) is computed.
+int bh_carve(BhBuffers &b, int n, void *base, size_t bytes, size_t *used);
 
 struct BhStepArgs {
     const double2 *pos;

@@ -1829,71 +1829,109 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // ------------------------------------------------------------------ buffers
 
-int bh_alloc(BhBuffers &b, int n)
+// Every device array of the pipeline for n bodies, taken from `alloc` (hipMalloc for a handle's
+// own buffers, a bump pointer for buffers carved out of a caller-provided arena).
+template <typename Alloc>
+static int bh_layout(BhBuffers &b, int n, Alloc &&alloc)
 {
     b.n = n;
     b.node_cap = 2 * (size_t)n + 8;
     b.sort_blocks = sort_blocks(n);
-    NB_TRY(dev_alloc(b.box, 4));
-    NB_TRY(dev_alloc(b.cut, 4));
-    NB_TRY(dev_alloc(b.leaf_sum, 4 * (size_t)n));
-    NB_TRY(dev_alloc(b.chunk_info, (size_t)n / 64 + 2));
-    NB_TRY(dev_alloc(b.bbox_part, 4 * BBOX_BLOCKS));
+    NB_TRY(alloc(b.box, 4));
+    NB_TRY(alloc(b.cut, 4));
+    NB_TRY(alloc(b.leaf_sum, 4 * (size_t)n));
+    NB_TRY(alloc(b.chunk_info, (size_t)n / 64 + 2));
+    NB_TRY(alloc(b.bbox_part, 4 * BBOX_BLOCKS));
     for (int k = 0; k < 2; ++k) {
-        NB_TRY(dev_alloc(b.keys[k], (size_t)n));
-        NB_TRY(dev_alloc(b.idx[k], (size_t)n));
+        NB_TRY(alloc(b.keys[k], (size_t)n));
+        NB_TRY(alloc(b.idx[k], (size_t)n));
     }
-    NB_TRY(dev_alloc(b.hist, (size_t)SORT_BINS * b.sort_blocks));
-    NB_TRY(dev_alloc(b.hist_totals, SORT_BINS));
-    NB_TRY(dev_alloc(b.posm_s, (size_t)n));
-    NB_TRY(dev_alloc(b.node_meta, b.node_cap));
-    NB_TRY(dev_alloc(b.split, (size_t)n + 256));  // one Split<2> (16 bytes) per frontier slot
-    NB_TRY(dev_alloc(b.level_start, BH_MAX_DEPTH + 2));
-    NB_TRY(dev_alloc(b.bsum, BH_SCAN_BLOCKS));
-    NB_TRY(dev_alloc(b.node_com, 4 * b.node_cap));
-    NB_TRY(dev_alloc(b.node_rec, b.node_cap));
-    NB_TRY(dev_alloc(b.node_child, b.node_cap));
-    NB_TRY(dev_alloc(b.tlist, (size_t)n));
-    NB_TRY(dev_alloc(b.tcount, 4));
-    NB_TRY(dev_alloc(b.tblock, target_list_blocks(n)));
-    NB_TRY(dev_alloc(b.counters, 8));
-    {
-        void *h = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
-            return fail(NB_ERR_NOMEM, "hipHostMalloc failed");
-        b.levels_host = (uint32_t *)h;
-        *b.levels_host = 0u;
+    NB_TRY(alloc(b.hist, (size_t)SORT_BINS * b.sort_blocks));
+    NB_TRY(alloc(b.hist_totals, SORT_BINS));
+    NB_TRY(alloc(b.posm_s, (size_t)n));
+    NB_TRY(alloc(b.node_meta, b.node_cap));
+    NB_TRY(alloc(b.split, (size_t)n + 256));  // one Split<2> (16 bytes) per frontier slot
+    NB_TRY(alloc(b.level_start, BH_MAX_DEPTH + 2));
+    NB_TRY(alloc(b.bsum, BH_SCAN_BLOCKS));
+    NB_TRY(alloc(b.node_com, 4 * b.node_cap));
+    NB_TRY(alloc(b.node_rec, b.node_cap));
+    NB_TRY(alloc(b.node_child, b.node_cap));
+    NB_TRY(alloc(b.tlist, (size_t)n));
+    NB_TRY(alloc(b.tcount, 4));
+    NB_TRY(alloc(b.tblock, target_list_blocks(n)));
+    NB_TRY(alloc(b.counters, 8));
+    return NB_OK;
+}
+
+int bh_alloc(BhBuffers &b, int n)
+{
+    b.owned = true;
+    NB_TRY(bh_layout(b, n, [](auto *&p, size_t count) { return dev_alloc(p, count); }));
+    void *h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
+        return fail(NB_ERR_NOMEM, "hipHostMalloc failed");
+    b.levels_host = (uint32_t *)h;
+    *b.levels_host = 0u;
+    return NB_OK;
+}
+
+// The same arrays laid out one after the other (each on a 256-byte boundary, with the slack
+// dev_alloc gives) in `arena`; nothing is allocated.  base == nullptr only measures: *used gets the
+// bytes n bodies need.  Such buffers have no host-visible level word: the per-level build kernels
+// are launched for every level each step.
+int bh_carve(BhBuffers &b, int n, void *base, size_t bytes, size_t *used)
+{
+    size_t off = 0;
+    bool fits = true;
+    b = BhBuffers();
+    b.owned = false;
+    NB_TRY(bh_layout(b, n, [&](auto *&p, size_t count) {
+        using T = std::remove_reference_t<decltype(*p)>;
+        const size_t need = (count * sizeof(T) + 256 + 255) & ~(size_t)255;
+        if (base && off + need > bytes)
+            fits = false;
+        p = (base && fits) ? (T *)((char *)base + off) : nullptr;
+        off += need;
+        return (int)NB_OK;
+    }));
+    if (used)
+        *used = off;
+    if (base && !fits) {
+        b = BhBuffers();
+        return fail(NB_ERR_OVERFLOW, "bh_carve: the arena is too small for " + std::to_string(n) + " bodies");
     }
     return NB_OK;
 }
 
 void bh_free(BhBuffers &b)
 {
-    (void)hipFree(b.box);
-    (void)hipFree(b.cut);
-    (void)hipFree(b.leaf_sum);
-    (void)hipFree(b.chunk_info);
-    (void)hipFree(b.bbox_part);
-    for (int k = 0; k < 2; ++k) {
-        (void)hipFree(b.keys[k]);
-        (void)hipFree(b.idx[k]);
+    if (b.owned) {
+        (void)hipFree(b.box);
+        (void)hipFree(b.cut);
+        (void)hipFree(b.leaf_sum);
+        (void)hipFree(b.chunk_info);
+        (void)hipFree(b.bbox_part);
+        for (int k = 0; k < 2; ++k) {
+            (void)hipFree(b.keys[k]);
+            (void)hipFree(b.idx[k]);
+        }
+        (void)hipFree(b.hist);
+        (void)hipFree(b.hist_totals);
+        (void)hipFree(b.posm_s);
+        (void)hipFree(b.node_meta);
+        (void)hipFree(b.split);
+        (void)hipFree(b.level_start);
+        (void)hipFree(b.bsum);
+        (void)hipFree(b.node_com);
+        (void)hipFree(b.node_rec);
+        (void)hipFree(b.node_child);
+        (void)hipFree(b.tlist);
+        (void)hipFree(b.tcount);
+        (void)hipFree(b.tblock);
+        (void)hipFree(b.counters);
+        if (b.levels_host)
+            (void)hipHostFree(b.levels_host);
     }
-    (void)hipFree(b.hist);
-    (void)hipFree(b.hist_totals);
-    (void)hipFree(b.posm_s);
-    (void)hipFree(b.node_meta);
-    (void)hipFree(b.split);
-    (void)hipFree(b.level_start);
-    (void)hipFree(b.bsum);
-    (void)hipFree(b.node_com);
-    (void)hipFree(b.node_rec);
-    (void)hipFree(b.node_child);
-    (void)hipFree(b.tlist);
-    (void)hipFree(b.tcount);
-    (void)hipFree(b.tblock);
-    (void)hipFree(b.counters);
-    if (b.levels_host)
-        (void)hipHostFree(b.levels_host);
     b = BhBuffers();
 }
 
