@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "n-body-simulation_amd")
 
 PUBLISHED_MS = 1509.0           # reference README.md:18, GPU Barnes-Hut N = 5M per iteration
+REHEARSAL = os.environ.get("NBODY_BENCH_REHEARSAL") == "1"
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, spec
 VALU_PEAK_TFLOPS = 157.3        # MI355X FP32 vector peak, spec (256 CU x 128 lanes x 2 x 2.4 GHz)
 FLOP_PER_INTERACTION = 20       # GPU Gems 3 ch. 31 convention
@@ -61,10 +62,17 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
 
     sim = nb.NBodySim(len(bodies), alg, params)
     sim.set_bodies(bodies)
-    eng = GpuEngine(sim, device)
-    if world > 1:
-        stepper = DistributedSim(eng)
+    if world > 1 and REHEARSAL:
+        # ranks sharing one GPU cannot form an RCCL group: the Python stepping layer over gloo
+        stepper = DistributedSim(GpuEngine(sim, device))
         step = lambda: stepper.update(1)  # noqa: E731
+    elif world > 1:
+        # the library's own communicator: one in-place ncclAllGather per step on the simulation's
+        # stream, no host synchronisation inside a step
+        cid = [nb.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(cid, src=0)
+        sim.comm_init(rank, world, cid[0])
+        step = lambda: sim.step_distributed(1)  # noqa: E731
     else:
         step = lambda: sim.update(1)  # noqa: E731
     for _ in range(warmup):
@@ -222,7 +230,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
     # NBODY_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo instead of RCCL -- runs the multi-rank
     # control flow on a one-GPU box (RCCL wants one GPU per rank); its numbers mean nothing
-    rehearsal = os.environ.get("NBODY_BENCH_REHEARSAL") == "1"
+    rehearsal = REHEARSAL
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -159,6 +159,23 @@ int nb_exchange_buffer(nb_sim *sim, void **device_ptr, size_t *chunk_records, si
 int nb_step_local(nb_sim *sim);
 int nb_step_finish(nb_sim *sim);
 
+/* The same exchange done by the library itself with RCCL (no counterpart in the reference, which
+ * is single-GPU): one in-place ncclAllGather of the position buffer per step, enqueued on the
+ * simulation's stream between that step's kernels, so the host never waits inside a step.
+ * librccl.so.1 is loaded on first use (by soname: a process that already holds an RCCL, e.g.
+ * PyTorch's, shares it); single-GPU users never load it.
+ *
+ *   rank 0:      nb_comm_unique_id(id, NB_COMM_ID_BYTES); hand the bytes to every rank (any channel)
+ *   every rank:  hipSetDevice(its GPU); nb_create; nb_set_bodies (same bodies everywhere);
+ *                nb_comm_init(sim, rank, world, id)        -- collective; also sets the partition
+ *                nb_step_distributed(sim, nsteps)          -- collective; asynchronous on the stream
+ *
+ * With world = 1 the steps are those of nb_step. */
+#define NB_COMM_ID_BYTES 128
+int nb_comm_unique_id(void *id, size_t bytes);
+int nb_comm_init(nb_sim *sim, int rank, int world, const void *id);
+int nb_step_distributed(nb_sim *sim, int nsteps);
+
 /* ---- introspection used by the tests and the benchmark ---- */
 
 enum nb_debug_array {
@@ -189,7 +206,8 @@ int nb_debug_read(nb_sim *sim, int which, void *out, size_t bytes, size_t *writt
  * collect the NB_DBG_COUNTERS statistics (slower traversal).
  * nb_stage_ms: mean milliseconds per stage over the steps (or nb_compute_accel calls) since the
  * previous nb_stage_ms call or since timing was switched on:
- * [0] bbox [1] keys [2] sort [3] build [4] com [5] force+integrate [6] other. */
+ * [0] bbox [1] keys [2] sort [3] build [4] com [5] force+integrate [6] the position exchange of
+ * nb_step_distributed (0 otherwise). */
 int nb_set_stage_timing(nb_sim *sim, int on);
 int nb_stage_ms(nb_sim *sim, float *out, int count);
 
@@ -282,6 +300,8 @@ int nb3_set_partition(nb_sim3 *sim, int rank, int world);
 int nb3_exchange_buffer(nb_sim3 *sim, void **device_ptr, size_t *chunk_records, size_t *record_bytes);
 int nb3_step_local(nb_sim3 *sim);
 int nb3_step_finish(nb_sim3 *sim);
+int nb3_comm_init(nb_sim3 *sim, int rank, int world, const void *id); /* id: from nb_comm_unique_id */
+int nb3_step_distributed(nb_sim3 *sim, int nsteps);
 /* `which` is an nb_debug_array.  Differences from nb_debug_read: NB_DBG_BBOX is 6 doubles
  * (topLeft.x, topLeft.y, botRight.x, botRight.y, upper z, lower z); keys hold 3 bits per level from
  * bit 61 down (at most 20 levels: bodies that share a cell of level 20, a millionth of the box, share a

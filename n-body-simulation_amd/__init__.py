@@ -59,7 +59,8 @@ ABI_SYMBOLS = [
     "nb_default_params", "nb_init_scenario", "nb_create", "nb_destroy", "nb_setup", "nb_set_bodies",
     "nb_step", "nb_compute_accel", "nb_read_bodies", "nb_sync", "nb_set_stream", "nb_set_partition",
     "nb_exchange_buffer", "nb_step_local", "nb_step_finish", "nb_debug_read", "nb_set_stage_timing",
-    "nb_stage_ms", "nb_diagnostics", "nb_refresh_order", "nb_compute_accel_static", "nb_last_error", "nb_version",
+    "nb_stage_ms", "nb_diagnostics", "nb_refresh_order", "nb_compute_accel_static", "nb_comm_unique_id", "nb_comm_init", "nb_step_distributed",
+    "nb3_comm_init", "nb3_step_distributed", "nb_last_error", "nb_version",
     "nb3_init_scenario", "nb3_create", "nb3_destroy", "nb3_setup", "nb3_set_bodies", "nb3_step",
     "nb3_compute_accel", "nb3_read_bodies", "nb3_sync", "nb3_debug_read", "nb3_set_stage_timing", "nb3_stage_ms",
     "nb3_diagnostics", "nb3_set_stream", "nb3_set_partition", "nb3_exchange_buffer", "nb3_step_local", "nb3_step_finish",
@@ -121,6 +122,11 @@ def load_library(path=None):
     lib.nb_diagnostics.argtypes = [vp, C.POINTER(C.c_double), i]
     lib.nb_refresh_order.argtypes = [vp]
     lib.nb_compute_accel_static.argtypes = [vp, vp, vp, vp]
+    lib.nb_comm_unique_id.argtypes = [vp, C.c_size_t]
+    lib.nb_comm_init.argtypes = [vp, i, i, vp]
+    lib.nb_step_distributed.argtypes = [vp, i]
+    lib.nb3_comm_init.argtypes = [vp, i, i, vp]
+    lib.nb3_step_distributed.argtypes = [vp, i]
     lib.nb3_init_scenario.argtypes = [i, i, u, C.c_double, vp]
     lib.nb3_create.argtypes = [C.POINTER(Params), i, i, C.POINTER(vp)]
     lib.nb3_destroy.argtypes = [vp]
@@ -152,6 +158,16 @@ def load_library(path=None):
 def _check(rc):
     if rc != 0:
         raise NBodyError("nbody error %d: %s" % (rc, load_library().nb_last_error().decode()))
+
+
+COMM_ID_BYTES = 128  # NB_COMM_ID_BYTES
+
+
+def comm_unique_id():
+    """The bytes rank 0 hands to every rank for comm_init (ncclGetUniqueId)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load_library().nb_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
 
 
 def default_params(**overrides):
@@ -228,6 +244,13 @@ class NBodySim:
     def step_local(self):
         _check(self._lib.nb_step_local(self._h))
 
+    def comm_init(self, rank, world, comm_id):
+        """Joins the RCCL communicator (collective over the ranks); sets the partition."""
+        _check(self._lib.nb_comm_init(self._h, rank, world, C.c_char_p(comm_id)))
+
+    def step_distributed(self, nsteps=1):
+        _check(self._lib.nb_step_distributed(self._h, nsteps))
+
     def step_finish(self):
         _check(self._lib.nb_step_finish(self._h))
 
@@ -243,7 +266,7 @@ class NBodySim:
     def stage_ms(self):
         out = (C.c_float * 8)()
         _check(self._lib.nb_stage_ms(self._h, out, 8))
-        names = ["bbox", "keys", "sort", "build", "com", "force", "other"]
+        names = ["bbox", "keys", "sort", "build", "com", "force", "exchange"]
         return {k: out[i] for i, k in enumerate(names)}
 
     def refresh_order(self):
@@ -322,6 +345,12 @@ class NBodySim3:
     def step_local(self):
         _check(self._lib.nb3_step_local(self._h))
 
+    def comm_init(self, rank, world, comm_id):
+        _check(self._lib.nb3_comm_init(self._h, rank, world, C.c_char_p(comm_id)))
+
+    def step_distributed(self, nsteps=1):
+        _check(self._lib.nb3_step_distributed(self._h, nsteps))
+
     def step_finish(self):
         _check(self._lib.nb3_step_finish(self._h))
 
@@ -354,7 +383,7 @@ class NBodySim3:
     def stage_ms(self):
         out = (C.c_float * 8)()
         _check(self._lib.nb3_stage_ms(self._h, out, 8))
-        names = ["bbox", "keys", "sort", "build", "com", "force", "other"]
+        names = ["bbox", "keys", "sort", "build", "com", "force", "exchange"]
         return {k: out[i] for i, k in enumerate(names)}
 
     def order(self):

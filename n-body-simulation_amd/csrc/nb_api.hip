@@ -210,6 +210,8 @@ void release(nb_sim *s)
     (void)hipFree(s->part);
     (void)hipFree(s->ds_meta);
     bh_free(s->bh);
+    comm_destroy(s->comm);
+    s->comm = nullptr;
     s->timer.destroy();
     if (s->own_stream && s->stream)
         (void)hipStreamDestroy(s->stream);
@@ -482,6 +484,53 @@ int nb_step(nb_sim *s, int nsteps)
         NB_TRY(collect_timing(s));
         if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= interval)
             NB_TRY(nb_refresh_order(s));
+    }
+    return NB_OK;
+}
+
+int nb_comm_unique_id(void *id, size_t bytes)
+{
+    if (bytes < COMM_ID_BYTES)
+        return fail(NB_ERR_ARG, "nb_comm_unique_id: the buffer must hold NB_COMM_ID_BYTES bytes");
+    return comm_unique_id(id);
+}
+
+int nb_comm_init(nb_sim *s, int rank, int world, const void *id)
+{
+    if (!s || !id)
+        return fail(NB_ERR_ARG, "nb_comm_init: NULL argument");
+    if (s->comm)
+        return fail(NB_ERR_STATE, "nb_comm_init: the simulation already has a communicator");
+    int device = -1;
+    NB_HIP(hipGetDevice(&device));
+    if (device != s->device)
+        return fail(NB_ERR_STATE, "nb_comm_init: the handle's device is not the current one");
+    NB_TRY(nb_set_partition(s, rank, world));
+    return comm_create(&s->comm, rank, world, id);
+}
+
+int nb_step_distributed(nb_sim *s, int nsteps)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_step_distributed: sim is NULL");
+    if (nsteps < 0)
+        return fail(NB_ERR_ARG, "nb_step_distributed: nsteps < 0");
+    if (!s->comm)
+        return fail(NB_ERR_STATE, "nb_step_distributed: call nb_comm_init first");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb_step_distributed: no bodies were set");
+    if (s->mid_step)
+        return fail(NB_ERR_STATE, "nb_step_distributed: a split step is in flight");
+    for (int k = 0; k < nsteps; ++k) {
+        NB_TRY(step_local(s, 1));
+        // the new positions of every rank's slice, in place, ordered on the stream with the kernels
+        // before and after: the host does not wait
+        double2 *buf = s->alg == NB_ALG_DIRECT ? s->pos2 : s->pos;
+        if (s->world > 1)
+            NB_TRY(comm_all_gather_f64(s->comm, (double *)buf, 2 * s->chunk, s->stream));
+        mark(s, s->alg == NB_ALG_DIRECT ? 2 : 7);
+        NB_TRY(step_finish(s));
+        NB_TRY(collect_timing(s));
     }
     return NB_OK;
 }

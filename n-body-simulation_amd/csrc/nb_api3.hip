@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "nb_bh.h"
+#include "nb_comm.h"
 #include "nb_common.h"
 #include "nb_timing.h"
 #include "nb_dim3.h"
@@ -38,6 +39,8 @@ struct nb_sim3 {
     size_t chunk = 0;
     int t0 = 0, t1 = 0;
     bool mid_step = false;
+    Comm *comm = nullptr;  // RCCL communicator of nb3_comm_init (null: none)
+    int device = 0;
     size_t part_cap = 0;  // doubles in ds.part
 
     Direct3State ds;
@@ -219,6 +222,8 @@ void release(nb_sim3 *s)
     (void)hipFree(s->ds.part);
     (void)hipFree(s->ds.meta);
     bh3_free(s->bh);
+    comm_destroy(s->comm);
+    s->comm = nullptr;
     s->timer.destroy();
     if (s->own_stream && s->stream)
         (void)hipStreamDestroy(s->stream);
@@ -330,7 +335,9 @@ int nb3_create(const nb_params *params, int n, int alg, nb_sim3 **out)
         if (rc == NB_OK)
             rc = r;
     };
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
+    if (hipGetDevice(&s->device) != hipSuccess)
+        chk(fail(NB_ERR_HIP, "hipGetDevice failed"));
+    if (rc == NB_OK && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
         chk(fail(NB_ERR_HIP, "hipStreamCreate failed"));
     s->own_stream = rc == NB_OK;
     s->t1 = n;
@@ -434,6 +441,44 @@ int nb3_step(nb_sim3 *s, int nsteps)
             NB_TRY(read_state(s, b.data(), 0.0));
             NB_TRY(load_bodies(s, b.data(), s->n));
         }
+    }
+    return NB_OK;
+}
+
+int nb3_comm_init(nb_sim3 *s, int rank, int world, const void *id)
+{
+    if (!s || !id)
+        return fail(NB_ERR_ARG, "nb3_comm_init: NULL argument");
+    if (s->comm)
+        return fail(NB_ERR_STATE, "nb3_comm_init: the simulation already has a communicator");
+    int device = -1;
+    NB_HIP(hipGetDevice(&device));
+    if (device != s->device)
+        return fail(NB_ERR_STATE, "nb3_comm_init: the handle's device is not the current one");
+    NB_TRY(nb3_set_partition(s, rank, world));
+    return comm_create(&s->comm, rank, world, id);
+}
+
+int nb3_step_distributed(nb_sim3 *s, int nsteps)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb3_step_distributed: sim is NULL");
+    if (nsteps < 0)
+        return fail(NB_ERR_ARG, "nb3_step_distributed: nsteps < 0");
+    if (!s->comm)
+        return fail(NB_ERR_STATE, "nb3_step_distributed: call nb3_comm_init first");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb3_step_distributed: no bodies were set");
+    if (s->mid_step)
+        return fail(NB_ERR_STATE, "nb3_step_distributed: a split step is in flight");
+    for (int k = 0; k < nsteps; ++k) {
+        NB_TRY(step_local(s, 1));
+        double *buf = s->alg == NB_ALG_DIRECT ? s->pos2 : s->pos;
+        if (s->world > 1)
+            NB_TRY(comm_all_gather_f64(s->comm, buf, 3 * s->chunk, s->stream));
+        mark(s, s->alg == NB_ALG_DIRECT ? 2 : 7);
+        NB_TRY(step_finish(s));
+        NB_TRY(collect_timing(s));
     }
     return NB_OK;
 }

@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "nb_bh.h"
+#include "nb_comm.h"
 #include "nb_common.h"
 #include "nb_timing.h"
 
@@ -39,6 +40,7 @@ struct nb_sim {
     size_t chunk = 0;
     int t0 = 0, t1 = 0;
     bool mid_step = false;
+    nb::Comm *comm = nullptr;  // RCCL communicator of nb_comm_init (null: none)
 
     // direct sum
     double2 *part = nullptr;

@@ -14,7 +14,12 @@
 // --integrator euler|leapfrog, --energy (prints the conserved quantities before and after the
 // run), --thickness T (three-dimensional run: the scenario's bodies get heights in [-T, T]; frames
 // are then "NBDUMP3" records {x, y, z, vx, vy, vz, mass} and images are the x-y projection),
-// --quiet.
+// --gpus G (one process per GPU: the program starts G ranks of itself, each advances a slice of
+// the bodies and the positions are all-gathered with RCCL every step; rank 0 reports), --quiet.
+#include <hip/hip_runtime_api.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -135,6 +140,7 @@ int main(int argc, char **argv)
     bool quiet = false, energy = false;
     double thickness = -1;  // >= 0: three-dimensional run
     int integrator = NB_INT_EULER;
+    int gpus = 1;
     std::vector<const char *> pos;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -169,6 +175,8 @@ int main(int argc, char **argv)
             energy = true;
         else if (a == "--thickness")
             thickness = std::atof(next("--thickness"));
+        else if (a == "--gpus")
+            gpus = std::atoi(next("--gpus"));
         else if (a == "--quiet")
             quiet = true;
         else
@@ -205,6 +213,75 @@ int main(int argc, char **argv)
     if (dump_every < 1)
         dump_every = 1;
 
+    // ---- one process per GPU ----
+    // The ranks are started here, before anything in this process has touched the GPU.  Rank 0
+    // makes the communicator id and hands it to the others through pipes.
+    int rank = 0;
+    unsigned char comm_id[NB_COMM_ID_BYTES];
+    if (gpus < 1 || gpus > 64) {
+        std::cout << "ERROR: --gpus must be 1..64" << std::endl;
+        return -1;
+    }
+    if (gpus > 1) {
+        if (!dump.empty() || energy) {
+            std::cout << "ERROR: --dump and --energy need one process to hold every velocity; not with --gpus > 1" << std::endl;
+            return -1;
+        }
+        std::vector<int> fds(2 * (size_t)gpus, -1);
+        for (int r = 1; r < gpus; ++r)
+            if (pipe(&fds[2 * (size_t)r]) != 0) {
+                std::perror("pipe");
+                return EXIT_FAILURE;
+            }
+        std::vector<pid_t> kids;
+        bool child = false;
+        for (int r = 0; r < gpus && !child; ++r) {
+            const pid_t pid = fork();
+            if (pid < 0) {
+                std::perror("fork");
+                return EXIT_FAILURE;
+            }
+            if (pid == 0) {
+                child = true;
+                rank = r;
+            } else
+                kids.push_back(pid);
+        }
+        if (!child) {
+            int failed = 0;
+            for (pid_t pid : kids) {
+                int st = 0;
+                if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
+                    failed = 1;
+            }
+            return failed ? EXIT_FAILURE : 0;
+        }
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < gpus) {
+            if (rank == 0)
+                std::cout << "ERROR: --gpus " << gpus << " but " << ndev << " GPU(s) are visible" << std::endl;
+            return EXIT_FAILURE;
+        }
+        if (hipSetDevice(rank) != hipSuccess) {
+            std::cerr << "hipSetDevice(" << rank << ") failed" << std::endl;
+            return EXIT_FAILURE;
+        }
+        if (rank == 0) {
+            nbody::check(nb_comm_unique_id(comm_id, sizeof(comm_id)), "nb_comm_unique_id");
+            for (int r = 1; r < gpus; ++r)
+                if (write(fds[2 * (size_t)r + 1], comm_id, sizeof(comm_id)) != (ssize_t)sizeof(comm_id)) {
+                    std::perror("write");
+                    return EXIT_FAILURE;
+                }
+        } else if (read(fds[2 * (size_t)rank], comm_id, sizeof(comm_id)) != (ssize_t)sizeof(comm_id)) {
+            std::perror("read");
+            return EXIT_FAILURE;
+        }
+        quiet = quiet || rank != 0;
+        if (rank != 0)
+            ppm.clear();
+    }
+
     std::FILE *f = nullptr;
     if (!dump.empty()) {
         f = std::fopen(dump.c_str(), "wb");
@@ -217,6 +294,8 @@ int main(int argc, char **argv)
         // the same loop over the three-dimensional object
         nbody::NBodySim3 nb3(nBodies, alg, &params, seed);
         nb3.setup(scenario, thickness);
+        if (gpus > 1)
+            nb3.commInit(rank, gpus, comm_id);
         std::vector<nb_body> flat;
         const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < iters; ++i) {
@@ -243,11 +322,13 @@ int main(int argc, char **argv)
             std::fclose(f);
         if (!quiet)
             std::cout << (alg == NB_ALG_DIRECT ? "direct sum" : "Barnes-Hut") << " 3-D N=" << nBodies << " sim=" << sim
-                      << " iters=" << iters << " : " << ms / iters << " ms/step" << std::endl;
+                      << " iters=" << iters << " gpus=" << gpus << " : " << ms / iters << " ms/step" << std::endl;
         return 0;
     }
     nbody::NBodySim nb(nBodies, alg, &params, seed);
     nb.setup(scenario);
+    if (gpus > 1)
+        nb.commInit(rank, gpus, comm_id);
     auto print_energy = [&](const char *when) {
         double d[8];
         nb.diagnostics(d);
@@ -278,6 +359,6 @@ int main(int argc, char **argv)
         print_energy("end");
     if (!quiet)
         std::cout << (alg == NB_ALG_DIRECT ? "direct sum" : "Barnes-Hut") << " N=" << nBodies << " sim=" << sim
-                  << " iters=" << iters << " : " << ms / iters << " ms/step" << std::endl;
+                  << " iters=" << iters << " gpus=" << gpus << " : " << ms / iters << " ms/step" << std::endl;
     return 0;
 }

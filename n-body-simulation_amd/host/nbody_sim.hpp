@@ -39,7 +39,20 @@ public:
 
     void setup(int sim) { check(nb_setup(sim_, sim, seed_), "nb_setup"); }
     void setBodies(const nb_body *b) { check(nb_set_bodies(sim_, b, n_), "nb_set_bodies"); }
-    void update(int steps = 1) { check(nb_step(sim_, steps), "nb_step"); }
+    void update(int steps = 1)
+    {
+        if (distributed_)
+            check(nb_step_distributed(sim_, steps), "nb_step_distributed");
+        else
+            check(nb_step(sim_, steps), "nb_step");
+    }
+    // One process per GPU: joins the RCCL communicator (id from nb_comm_unique_id on rank 0); update()
+    // then advances this rank's slice and all-gathers the positions.
+    void commInit(int rank, int world, const void *id)
+    {
+        check(nb_comm_init(sim_, rank, world, id), "nb_comm_init");
+        distributed_ = true;
+    }
     void readDeviceBodies() { check(nb_read_bodies(sim_, bodies_.data()), "nb_read_bodies"); }
     nb_body *getBodies() { return bodies_.data(); }
     void sync() { check(nb_sync(sim_), "nb_sync"); }
@@ -51,6 +64,7 @@ private:
     int n_;
     unsigned seed_;
     nb_sim *sim_ = nullptr;
+    bool distributed_ = false;
     std::vector<nb_body> bodies_;
 };
 
@@ -67,7 +81,18 @@ public:
 
     void setup(int sim, double thickness) { check(nb3_setup(sim_, sim, seed_, thickness), "nb3_setup"); }
     void setBodies(const nb_body3 *b) { check(nb3_set_bodies(sim_, b, n_), "nb3_set_bodies"); }
-    void update(int steps = 1) { check(nb3_step(sim_, steps), "nb3_step"); }
+    void update(int steps = 1)
+    {
+        if (distributed_)
+            check(nb3_step_distributed(sim_, steps), "nb3_step_distributed");
+        else
+            check(nb3_step(sim_, steps), "nb3_step");
+    }
+    void commInit(int rank, int world, const void *id)
+    {
+        check(nb3_comm_init(sim_, rank, world, id), "nb3_comm_init");
+        distributed_ = true;
+    }
     void readDeviceBodies() { check(nb3_read_bodies(sim_, bodies_.data()), "nb3_read_bodies"); }
     nb_body3 *getBodies() { return bodies_.data(); }
     void sync() { check(nb3_sync(sim_), "nb3_sync"); }
@@ -77,6 +102,7 @@ private:
     int n_;
     unsigned seed_;
     nb_sim3 *sim_ = nullptr;
+    bool distributed_ = false;
     std::vector<nb_body3> bodies_;
 };
 

@@ -147,3 +147,24 @@ def test_thickness_runs_the_3d_path(nb, tmp_path, prog, alg):
             assert np.array_equal(frame[:, 6], b["mass"])
     assert np.abs(frames[-1][1][:-1, 2]).max() > 1.0e10  # the bodies do have heights
     assert (tmp_path / "f_000004.ppm").exists()
+
+
+def test_gpus_flag_is_checked_before_anything_runs():
+    r = subprocess.run([binary("BarnesHut"), "10", "0", "1", "--gpus", "0"], capture_output=True, text=True)
+    assert r.returncode == 255 and "--gpus must be 1..64" in r.stdout
+    r = subprocess.run([binary("BarnesHut"), "10", "0", "1", "--gpus", "2", "--dump", "/dev/null"],
+                       capture_output=True, text=True)
+    assert r.returncode == 255 and "not with --gpus > 1" in r.stdout
+
+
+@pytest.mark.gpu
+def test_more_ranks_than_gpus_fail_with_a_message(nb):
+    """--gpus G starts G processes, one per GPU, that step together over RCCL.  A one-GPU box cannot
+    form that group: every rank must find that out and leave, none may hang."""
+    import torch
+
+    have = torch.cuda.device_count()
+    r = subprocess.run([binary("BarnesHut"), "1000", "0", "2", "--gpus", str(have + 1)], capture_output=True, text=True,
+                       timeout=100)
+    assert r.returncode == 1
+    assert "--gpus %d but %d GPU(s) are visible" % (have + 1, have) in r.stdout

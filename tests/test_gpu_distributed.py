@@ -90,6 +90,37 @@ def test_distributed_stepper_world1_matches_plain_update_3d(nb, oracle, nccl_gro
     assert np.array_equal(a["vel"], ref["vel"])
 
 
+@pytest.mark.parametrize("dims", [2, 3])
+@pytest.mark.parametrize("alg", [0, 1])
+def test_native_rccl_world1_matches_plain_update(nb, oracle, alg, dims):
+    """nb_comm_init / nb_step_distributed: the library's own RCCL communicator (a second one beside
+    torch's, sharing its librccl), world size 1 -- all a one-GPU box can form.  The steps must be
+    those of nb_step to the bit, the host must not be needed between them, and the exchange shows up
+    as its own timing stage."""
+    n = 4099
+    b = oracle.scenario(0, n, 3) if dims == 2 else oracle.scenario3(0, n, 3, thickness=5.0e10)
+    Sim = nb.NBodySim if dims == 2 else nb.NBodySim3
+    cid = nb.comm_unique_id()
+    assert len(cid) == nb.COMM_ID_BYTES
+    with Sim(n, alg) as plain, Sim(n, alg) as part:
+        plain.set_bodies(b)
+        part.set_bodies(b)
+        with pytest.raises(nb.NBodyError, match="comm_init first"):
+            part.step_distributed(1)
+        part.comm_init(0, 1, cid)
+        with pytest.raises(nb.NBodyError, match="already has a communicator"):
+            part.comm_init(0, 1, cid)
+        part.set_stage_timing(True, counters=False)
+        plain.update(6)
+        part.step_distributed(6)  # six steps enqueued in one call
+        ms = part.stage_ms()
+        a = part.read_bodies()
+        ref = plain.read_bodies()
+    assert np.array_equal(a["pos"], ref["pos"])
+    assert np.array_equal(a["vel"], ref["vel"])
+    assert ms["force"] > 0 and ms["exchange"] >= 0
+
+
 @pytest.mark.parametrize("alg,dims,world", [(0, 2, 2), (1, 2, 2), (1, 2, 3), (0, 3, 2), (1, 3, 2)])
 def test_separate_processes_step_one_system_together(nb, oracle, tmp_path, alg, dims, world):
     """`world` processes, each with its own handle on the one GPU, advance one system through the
