@@ -361,6 +361,8 @@ static int load_bodies(nb_sim *s, const nb_body *b, int n)
                               hipMemcpyDeviceToDevice, s->stream));
     }
     NB_HIP(hipStreamSynchronize(s->stream));
+    if (s->alg == NB_ALG_BARNES_HUT)
+        NB_TRY(bh_prime(s->stream, s->bh, bh_args(s, 0)));
     s->steps_in_order = 0;
     return NB_OK;
 }

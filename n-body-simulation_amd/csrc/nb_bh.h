@@ -26,7 +26,8 @@ struct BhBuffers {
     uint32_t *idx[2] = {nullptr, nullptr};
     int sorted = 0;               // which of the two holds the sorted result (always 0: see bh_sort)
     uint32_t *cut = nullptr;      // [0] first tree level whose cells are never opened (32: none),
-                                  // [1] levels the keys are computed to
+                                  // [1] levels the keys are computed to, [2] first sort pass with work,
+                                  // [3] 1: this step builds the dense pyramid, 0: the level-by-level tree
     uint32_t *hist = nullptr;     // 256 x sort blocks
     uint32_t *hist_totals = nullptr;  // 256: keys per digit of the current pass
     int sort_blocks = 0;
@@ -42,14 +43,19 @@ struct BhBuffers {
                                   // or for a leaf minus its body's radius (sign bit set)
     float4 *node_rec = nullptr;   // traversal record {com.x, com.y, mass, w}: w = (width/theta)^2 for a
                                   // cell, -(radius + collision_th) for a leaf, internal units
-    uint2 *node_child = nullptr;  // x = first child << 3 | child count, y = float bits of the prune
-                                  // threshold: (collision_th - cell diagonal)^2, or -1
+    uint2 *node_child = nullptr;  // x = first child slot << 4 | mask of the child slots in use, y = float
+                                  // bits of the prune threshold: (collision_th - cell diagonal)^2, or -1
     uint32_t *tlist = nullptr;    // sorted positions of this rank's targets (multi-GPU), else unused
     uint32_t *tcount = nullptr;   // 1 entry: number of targets in tlist
     uint32_t *tblock = nullptr;   // per-block target counts (scratch of the compaction)
     unsigned long long *counters = nullptr;  // 8 statistics words
     uint32_t *levels_host = nullptr;  // pinned host word: tree levels of the last finished step
+    uint32_t *hint_host = nullptr;    // pinned host word: levels the keys of the last finished step held
     int launched = 0;                 // levels the per-level build kernels were launched for
+    uint2 *pc_range = nullptr;        // dense pyramid: first and one-past-last sorted body of every cell of the
+                                      // keys' last level (both zero: empty cell); null: no pyramid
+    bool use_pyr = false;             // this step's kernels are launched for the dense-pyramid build ...
+    int pyr_levels = -1;              // ... and can do keys of up to this many levels (-1: not launched)
 };
 
 int bh_alloc(BhBuffers &b, int n);
@@ -108,6 +114,7 @@ int leaf_finish(hipStream_t s, const uint32_t *chunk_info, int n, double *leaf_s
 
 // Individual stages (also driven one by one by the stage tests through nb_step).
 int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
+int bh_prime(hipStream_t s, BhBuffers &b, const BhStepArgs &a);  // after new bodies: learns the key depth (waits)
 int bh_keys(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
 int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
 int bh_build(hipStream_t s, BhBuffers &b, const BhStepArgs &a);

@@ -26,6 +26,17 @@
 
 namespace nb {
 
+// Dense pyramid: when the keys stop at a level L <= PYR_MAX_LEVEL (a closed level, or the depth cap
+// of the GPU-program tree), every cell of levels 0..L has a slot of its own in the node arrays,
+// cell c of level l at pyr_offset(l) + c (c = the cell's quadrant path, 2 bits a level), so the four
+// children of a cell are the consecutive slots pyr_offset(l + 1) + 4 c .. + 3 and nothing has to be
+// numbered or searched for.
+constexpr int PYR_MAX_LEVEL = 10;
+constexpr int PYR_SMALL_LEVEL = 9;  // deepest level the small-LDS variant of k_pyr_sub covers
+__host__ __device__ constexpr uint32_t pyr_offset(int l) { return (uint32_t)((((uint64_t)1 << (2 * l)) - 1) / 3); }
+constexpr uint32_t PYR_CELLS = pyr_offset(PYR_MAX_LEVEL + 1);        // cells of all levels
+constexpr uint32_t PYR_LEAF_CELLS = 1u << (2 * PYR_MAX_LEVEL);        // cells of the deepest level
+
 // ------------------------------------------------------------------ 1 bounding box
 
 constexpr int BBOX_BLOCKS = 1024;
@@ -72,7 +83,8 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const double2 *pos, int n,
 }
 
 __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk, double margin, int bucket_depth,
-                                                    double theta, double cth, double *box, uint32_t *cut)
+                                                    double theta, double cth, double *box, uint32_t *cut, int pyr_levels,
+                                                    uint32_t *hint_host)
 {
     double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
     for (int i = threadIdx.x; i < nblk; i += 256) {
@@ -140,6 +152,11 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         cut[1] = bucket_depth > 0 ? (uint32_t)bucket_depth
                                   : (first_closed < (uint32_t)BH_KEY_LEVELS ? first_closed : (uint32_t)BH_KEY_LEVELS);
         cut[2] = (uint32_t)sort_first_pass(2 * (int)cut[1]);
+        // The dense-pyramid build runs when the host launched its kernels (pyr_levels >= 0) and
+        // the keys stop at a level it covers; otherwise the level-by-level build does the step.
+        cut[3] = (pyr_levels >= 0 && (int)cut[1] <= pyr_levels) ? 1u : 0u;
+        if (hint_host)
+            *hint_host = cut[1];  // host-visible: sizes the next steps' launches (a stale value only costs speed)
     }
 }
 
@@ -149,8 +166,15 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     if (blocks > BBOX_BLOCKS)
         blocks = BBOX_BLOCKS;
     hipLaunchKernelGGL(k_bbox_partial, dim3(blocks), dim3(256), 0, s, a.pos, a.n, b.bbox_part);
+    // which build this step's kernels are launched for: the dense pyramid when the keys of the last
+    // finished step stopped at a level it covers
+    const uint32_t hint = (b.pc_range && b.hint_host) ? *(volatile const uint32_t *)b.hint_host : 0xffffffffu;
+    b.use_pyr = hint <= (uint32_t)PYR_MAX_LEVEL;
+    // the deepest key level the pyramid kernels of this step can do (the variant with the small LDS
+    // footprint when the keys of the previous steps fit it)
+    b.pyr_levels = !b.use_pyr ? -1 : (hint <= (uint32_t)PYR_SMALL_LEVEL ? PYR_SMALL_LEVEL : PYR_MAX_LEVEL);
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, a.bucket_depth,
-                       a.theta, a.collision_th, b.box, b.cut);
+                       a.theta, a.collision_th, b.box, b.cut, b.pyr_levels, b.hint_host);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -163,12 +187,20 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 // that level then share a key and end up in one leaf.  The keys go to the buffer the first sort
 // pass that has work (cut[2]) reads from (see sort_pairs).
 __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const double *box, const uint32_t *cut,
-                                              uint64_t *keys0, uint64_t *keys1, uint32_t *idx0, uint32_t *idx1)
+                                              uint64_t *keys0, uint64_t *keys1, uint32_t *idx0, uint32_t *idx1,
+                                              uint2 *pc_range)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
+    const int levels = (int)cut[1];
+    if (cut[3] != 0u) {
+        // dense-pyramid build: the {first, end} slots of the cells of the keys' last level start
+        // out empty (the leaf pass fills those that hold bodies)
+        const uint32_t cells = 1u << (2 * levels);
+        for (uint32_t j = (uint32_t)i; j < cells; j += gridDim.x * 256u)
+            pc_range[j] = make_uint2(0u, 0u);
+    }
     if (i >= n)
         return;
-    const int levels = (int)cut[1];
     double tlx = box[0], tly = box[1], brx = box[2], bry = box[3];
     const double2 p = pos[i];
     uint64_t k = 0;
@@ -188,10 +220,21 @@ __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const d
     (odd ? idx1 : idx0)[i] = (uint32_t)i;
 }
 
+// After new bodies were set: one bounding-box pass, waited for, so that the first step already
+// knows how deep its keys go (and with that, which build to launch).
+int bh_prime(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+{
+    if (!b.hint_host)
+        return NB_OK;
+    NB_TRY(bh_bbox(s, b, a));
+    NB_HIP(hipStreamSynchronize(s));
+    return NB_OK;
+}
+
 int bh_keys(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     hipLaunchKernelGGL(k_keys, dim3((a.n + 255) / 256), dim3(256), 0, s, a.pos, a.n, b.box, b.cut, b.keys[0], b.keys[1],
-                       b.idx[0], b.idx[1]);
+                       b.idx[0], b.idx[1], b.pc_range);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -874,6 +917,8 @@ int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node
 
 int bh_build(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
+    if (b.use_pyr)
+        return NB_OK;  // the dense pyramid is built from the leaf pass's output: see bh_com
     b.launched = launched_levels(b.levels_host);
     return build_tree(s, 2, b.keys[b.sorted], a.n, b.node_meta, b.split, b.level_start, b.bsum, b.counters, b.launched,
                       b.levels_host);
@@ -952,7 +997,8 @@ __device__ __forceinline__ void store_node(const ComArgs &a, uint32_t u, const u
     o[0] = make_double2(cx, cy);
     o[1] = make_double2(mtot, width);
     a.node_rec[u] = rec;
-    a.node_aux[u] = make_uint2((meta.z << 3) | (meta.w & 0xffu), __float_as_uint(prune));
+    // children of a node of the level-by-level tree are the consecutive slots meta.z .. + count - 1
+    a.node_aux[u] = make_uint2((meta.z << 4) | ((1u << (meta.w & 0xffu)) - 1u), __float_as_uint(prune));
 }
 
 // Sums over every run of bodies with one key (= every leaf with several bodies), left at the
@@ -967,7 +1013,7 @@ __device__ __forceinline__ void store_node(const ComArgs &a, uint32_t u, const u
 __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const uint32_t *idx, int n, const double2 *pos,
                                                    const double *mass, const double *radius, const double *box,
                                                    double inv_len, double inv_mass, float4 *posm_s, double *leaf_sum,
-                                                   uint32_t *chunk_info)
+                                                   uint32_t *chunk_info, const uint32_t *cut, uint2 *pc_range)
 {
     const double ox = 0.5 * (box[0] + box[2]), oy = 0.5 * (box[1] + box[3]);  // this step's origin
     const int lane = lane_id();
@@ -989,7 +1035,21 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
         posm_s[k] = make_float4((float)((p.x - ox) * inv_len), (float)((p.y - oy) * inv_len), (float)(sm * inv_mass),
                                 (float)(rm * inv_len));
     }
-    const uint64_t heads = __builtin_amdgcn_ballot_w64(valid && (k == 0 || key != prev));
+    const bool head = valid && (k == 0 || key != prev);
+    const uint64_t heads = __builtin_amdgcn_ballot_w64(head);
+    if (cut[3] != 0u) {
+        // Dense-pyramid build: a run of equal keys is the population of one cell of the level the
+        // keys stop at; its first and one-past-last sorted positions go to that cell's slot (the
+        // slots of empty cells were zeroed before this kernel).
+        const int shift = 62 - 2 * (int)cut[1];
+        const uint64_t next = (uint64_t)__shfl_down((unsigned long long)key, 1);
+        const uint64_t after = lane == 63 ? ((chunk + 64 < n) ? keys[chunk + 64] : ~0ull) : next;
+        const uint32_t cell = (uint32_t)(key >> shift);
+        if (head)
+            pc_range[cell].x = (uint32_t)k;
+        if (valid && (k + 1 >= n || after != key))
+            pc_range[cell].y = (uint32_t)k + 1u;
+    }
     // The bodies before the chunk's first head continue a run that started in an earlier chunk:
     // their sums go to the chunk's first slot (no run starts there, so nothing else uses it), and
     // k_leaf_finish adds them to that run.
@@ -1239,7 +1299,264 @@ __global__ __launch_bounds__(256) void k_com(ComArgs a, int d, int d_hi)
     com_level(a, d);
 }
 
+// ---- dense pyramid: tree, centres of mass and traversal records in two launches ----
+//
+// Slot pyr_offset(l) + c of the node arrays belongs to cell c of level l and holds the record of the
+// node that REPRESENTS the cell in the reference's tree as the traversal sees it:
+//   a cell of the last level L: its bodies as one leaf (one body: the body; several: the cell,
+//       which no body ever opens, or in the GPU-program tree a point mass);
+//   a cell with bodies in two or more quadrants: the cell itself, children = its four child slots
+//       (the child word carries a mask of the quadrants that hold bodies);
+//   a cell whose bodies all lie in one quadrant: a copy of that child's slot -- such a chain of
+//       cells shares its centre of mass, and a wider cell of the chain is accepted only if the
+//       narrowest is, with the same force;
+//   an empty cell: nothing (its parent's mask leaves it out).
+// What one cell hands to its parent:
+struct PyrCell {
+    double cx, cy, m, w;  // node_com: centre of mass, mass, cell x-width (or minus a body's radius)
+    float4 rec;           // node_rec
+    uint32_t child, prune;  // node_aux: first child slot << 4 | quadrant mask, prune threshold bits
+    uint32_t first, count;  // bodies (sorted positions)
+    uint32_t mchild, mlevel;  // node_meta z, w: first child slot, child slots | cell level << 8
+};
+
+__device__ __forceinline__ void pyr_store(const ComArgs &a, uint4 *node_meta, uint32_t slot, const PyrCell &c)
+{
+    node_meta[slot] = make_uint4(c.first, c.count, c.mchild, c.mlevel);
+    if (c.count == 0u)
+        return;
+    double2 *o = (double2 *)a.node_com + 2 * (size_t)slot;
+    o[0] = make_double2(c.cx, c.cy);
+    o[1] = make_double2(c.m, c.w);
+    a.node_rec[slot] = c.rec;
+    a.node_aux[slot] = make_uint2(c.child, c.prune);
+}
+
+__device__ __forceinline__ PyrCell pyr_load(const ComArgs &a, const uint4 *node_meta, uint32_t slot)
+{
+    PyrCell c;
+    const uint4 meta = node_meta[slot];
+    c.first = meta.x;
+    c.count = meta.y;
+    c.mchild = meta.z;
+    c.mlevel = meta.w;
+    if (c.count != 0u) {
+        const double2 *o = (const double2 *)a.node_com + 2 * (size_t)slot;
+        const double2 xy = o[0], mw = o[1];
+        c.cx = xy.x;
+        c.cy = xy.y;
+        c.m = mw.x;
+        c.w = mw.y;
+        c.rec = a.node_rec[slot];
+        const uint2 aux = a.node_aux[slot];
+        c.child = aux.x;
+        c.prune = aux.y;
+    }
+    return c;
+}
+
+// The leaf of one cell of the last level (the arithmetic of com_level's leaf branch).
+__device__ __forceinline__ PyrCell pyr_leaf(const ComArgs &a, uint32_t first, uint32_t end, int level, double width0)
+{
+    PyrCell c;
+    c.first = first;
+    c.count = end > first ? end - first : 0u;
+    c.child = 0u;
+    c.prune = __float_as_uint(-1.f);
+    c.mchild = 0u;
+    c.mlevel = (uint32_t)level << 8;
+    if (c.count == 1u) {
+        const uint32_t o = a.idx[first];
+        const double2 p = a.pos[o];
+        c.cx = p.x;
+        c.cy = p.y;
+        c.m = a.mass[o];
+        const float4 pm = a.posm_s[first];
+        c.rec = make_float4(pm.x, pm.y, pm.z, -(float)((a.radius[o] + a.cth) * a.inv_len));
+        c.w = -a.radius[o];
+        if (a.bucket) {
+            c.rec.w = 0.f;
+            c.w = 0.0;
+        }
+    } else if (c.count > 1u) {
+        const double2 *ls = (const double2 *)a.leaf_sum + 2 * (size_t)first;
+        const double2 sxy = ls[0], smr = ls[1];
+        c.m = smr.x;
+        float prune = -1.f;
+        multi_body_record(a, sxy.x, sxy.y, c.m, smr.y, width0, c.cx, c.cy, c.rec, c.w, prune);
+        c.prune = __float_as_uint(prune);
+    }
+    return c;
+}
+
+// A cell from its four child cells (ch[0..3] = quadrants TL,TR,BL,BR; child_slot = slot of ch[0]):
+// updateCenterMass (quadtree.cpp:187-228) for a cell with bodies in several quadrants.
+__device__ __forceinline__ PyrCell pyr_combine(const ComArgs &a, const PyrCell (&ch)[4], uint32_t child_slot, int level,
+                                               double width0)
+{
+    uint32_t mask = 0u, count = 0u, first = 0u;
+    int only = -1, nch = 0;
+#pragma unroll
+    for (int q = 3; q >= 0; --q)
+        if (ch[q].count != 0u) {
+            mask |= 1u << q;
+            count += ch[q].count;
+            first = ch[q].first;
+            only = q;
+            nch += 1;
+        }
+    if (nch == 1)
+        return ch[only];
+    PyrCell c;
+    c.first = first;
+    c.count = count;
+    c.child = 0u;
+    c.prune = __float_as_uint(-1.f);
+    c.mchild = 0u;
+    c.mlevel = (uint32_t)level << 8;
+    if (nch == 0)
+        return c;
+    double sx = 0.0, sy = 0.0, mtot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (ch[q].count != 0u) {
+            mtot += ch[q].m;
+            sx += ch[q].cx * ch[q].m;
+            sy += ch[q].cy * ch[q].m;
+        }
+    c.cx = sx / mtot;
+    c.cy = sy / mtot;
+    c.m = mtot;
+    float prune;
+    cell_record(a, c.cx, c.cy, mtot, level, width0, c.rec, c.w, prune);
+    c.prune = __float_as_uint(prune);
+    c.child = (child_slot << 4) | mask;
+    c.mchild = child_slot;
+    c.mlevel = 4u | ((uint32_t)level << 8);
+    return c;
+}
+
+// The pyramid is cut at level r = pyr_split(L): k_pyr_sub gives every cell of level r a block that
+// builds levels r..L under it bottom-up in LDS; k_pyr_top then builds levels r-1..0 in one block,
+// also in LDS (<= 1024 cells of level r come in, one load each).  Both hold at most 1365 cells.
+__host__ __device__ constexpr int pyr_split(int L) { return L > 5 ? 5 : (L > 4 ? L - 4 : 0); }
+constexpr int PYR_LDS_CELLS = 1365;  // 1 + 4 + 16 + 64 + 256 + 1024
+static_assert(PYR_MAX_LEVEL - pyr_split(PYR_MAX_LEVEL) <= 5 && pyr_split(PYR_MAX_LEVEL) <= 5, "LDS holds six levels");
+
+// Levels r .. L: one block per cell of level r.  CELLS: what the block's LDS holds -- 341 cells are
+// enough for L <= 9 (at most four levels under the block's cell), L = 10 needs 1365; the host picks
+// the variant from the depth of the previous steps' keys and tells k_bbox_final the deepest level
+// that variant can do (deeper keys fall back to the level-by-level build).
+template <int CELLS>
+__global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, const uint2 *pc_range)
+{
+    if (a.cut[3] == 0u)
+        return;
+    __shared__ PyrCell cells[CELLS];  // levels r..L of the block's cell
+    const int L = (int)a.cut[1];
+    const int r = pyr_split(L);
+    const int sub = L - r;
+    const uint32_t nroots = 1u << (2 * r), nleaf = 1u << (2 * sub);
+    const double width0 = a.box[2] - a.box[0];
+    for (uint32_t root = blockIdx.x; root < nroots; root += gridDim.x) {
+        for (uint32_t t = threadIdx.x; t < nleaf; t += 256) {
+            const uint32_t c = root * nleaf + t;
+            const uint2 range = pc_range[c];
+            const PyrCell leaf = pyr_leaf(a, range.x, range.y, L, width0);
+            cells[pyr_offset(sub) + t] = leaf;
+            pyr_store(a, node_meta, pyr_offset(L) + c, leaf);
+        }
+        __syncthreads();
+        for (int k = sub - 1; k >= 0; --k) {
+            const uint32_t cnt = 1u << (2 * k);
+            for (uint32_t t = threadIdx.x; t < cnt; t += 256) {
+                PyrCell ch[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ch[q] = cells[pyr_offset(k + 1) + 4 * t + q];
+                const uint32_t c = root * cnt + t;  // the cell's index within level r + k
+                const PyrCell me = pyr_combine(a, ch, pyr_offset(r + k + 1) + 4 * c, r + k, width0);
+                cells[pyr_offset(k) + t] = me;
+                pyr_store(a, node_meta, pyr_offset(r + k) + c, me);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Levels r - 1 .. 0 by one block, then the bookkeeping words.
+__global__ __launch_bounds__(1024) void k_pyr_top(ComArgs a, uint4 *node_meta, uint32_t *level_start,
+                                                  unsigned long long *counters)
+{
+    if (a.cut[3] == 0u)
+        return;
+    __shared__ PyrCell cells[PYR_LDS_CELLS];  // levels 0..r
+    const int L = (int)a.cut[1];
+    const int r = pyr_split(L);
+    const double width0 = a.box[2] - a.box[0];
+    for (uint32_t c = threadIdx.x; c < (1u << (2 * r)); c += 1024)
+        cells[pyr_offset(r) + c] = pyr_load(a, node_meta, pyr_offset(r) + c);
+    __syncthreads();
+    for (int l = r - 1; l >= 0; --l) {
+        const uint32_t cnt = 1u << (2 * l);
+        for (uint32_t c = threadIdx.x; c < cnt; c += 1024) {
+            PyrCell ch[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                ch[q] = cells[pyr_offset(l + 1) + 4 * c + q];
+            const PyrCell me = pyr_combine(a, ch, pyr_offset(l + 1) + 4 * c, l, width0);
+            cells[pyr_offset(l) + c] = me;
+            pyr_store(a, node_meta, pyr_offset(l) + c, me);
+        }
+        __syncthreads();
+    }
+    // every slot of levels 0..L is a node slot; the levels of this tree are the cell levels
+    if (threadIdx.x < BH_MAX_DEPTH + 2)
+        level_start[threadIdx.x] = threadIdx.x == 0 ? 0u : (threadIdx.x == 1 ? 1u : pyr_offset(L + 1));
+    if (threadIdx.x < 8)
+        counters[threadIdx.x] = threadIdx.x == 2 ? (unsigned long long)pyr_offset(L + 1)
+                                                 : (threadIdx.x == 3 ? (unsigned long long)(L + 1) : 0ull);
+}
+
 constexpr int COM_TOP_LEVELS = 5;  // levels 0..4: at most 341 cells
+
+// The whole level-by-level tree and its centres of mass by ONE block in one launch, for a step
+// whose kernels were launched for the dense pyramid but whose keys turned out deeper than it
+// covers (cut[3] == 0); returns at once otherwise.  Slow, complete, and rare: the host learns the
+// new depth from this very step.
+__global__ __launch_bounds__(256) void k_tree_fallback(ComArgs a, const uint64_t *keys, uint4 *node_meta, Split<2> *split,
+                                                       uint32_t *level_start, uint32_t *bsum, int n,
+                                                       unsigned long long *counters, uint32_t *levels_host)
+{
+    if (a.cut[3] != 0u)
+        return;
+    build_init(node_meta, level_start, n, counters);
+    int levels = 0;
+    for (int d = 0; d < BH_MAX_DEPTH - 2; ++d) {
+        __threadfence_block();
+        __syncthreads();  // level_start[d + 1] and the level's nodes are written
+        if (level_start[d + 1] == level_start[d])
+            break;  // uniform
+        levels = d + 1;
+        build_count<2>(keys, node_meta, split, level_start, bsum, d);
+        __threadfence_block();
+        __syncthreads();  // bsum[0] and the splits are written
+        build_emit<2>(node_meta, split, level_start, bsum, d);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[2] = level_start[levels];
+        counters[3] = (unsigned long long)levels;
+        if (levels_host)
+            *levels_host = (uint32_t)levels;
+    }
+    for (int dd = levels - 1; dd >= 0; --dd) {
+        com_level(a, dd);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
 
 int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
@@ -1263,8 +1580,24 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.cth = a.collision_th;
     c.bucket = a.bucket_depth > 0 ? 1 : 0;
     hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[b.sorted], b.idx[b.sorted], a.n, a.pos,
-                       a.mass, a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum, b.chunk_info);
+                       a.mass, a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum, b.chunk_info, b.cut, b.pc_range);
     NB_TRY(leaf_finish(s, b.chunk_info, a.n, b.leaf_sum, 2));
+    if (b.use_pyr) {
+        // Two launches build the tree, the centres of mass and the traversal records.  Should the
+        // keys of this very step go deeper than the pyramid covers (the device decides; the host
+        // only knew the previous steps), these kernels return at once and one block each of the
+        // level-by-level build and centre-of-mass kernels does the step instead: slower, complete.
+        const dim3 grid(1u << (2 * pyr_split(b.pyr_levels)));
+        if (b.pyr_levels > PYR_SMALL_LEVEL)
+            hipLaunchKernelGGL(k_pyr_sub<PYR_LDS_CELLS>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range);
+        else
+            hipLaunchKernelGGL(k_pyr_sub<341>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range);
+        hipLaunchKernelGGL(k_pyr_top, dim3(1), dim3(1024), 0, s, c, b.node_meta, b.level_start, b.counters);
+        hipLaunchKernelGGL(k_tree_fallback, dim3(1), dim3(256), 0, s, c, b.keys[b.sorted], b.node_meta, (Split<2> *)b.split,
+                           b.level_start, b.bsum, a.n, b.counters, b.levels_host);
+        NB_HIP(hipGetLastError());
+        return NB_OK;
+    }
     // levels beyond the ones the build launched per-level kernels for: one block, one launch
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
@@ -1282,10 +1615,10 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // ------------------------------------------------------------------ 6 traversal + integration
 
-// The stack holds one entry per opened node: {first child << 3 | child count, mask of the lanes
-// that opened it}; the (up to 4) siblings share the mask.  A round pops up to TR_ENTRIES entries
-// and gives each a group of 4 lanes: lane 4 e + i takes sibling i of the e-th entry from the top
-// (lanes past the entry's child count sit the round out).  Every visited node pushes at most one
+// The stack holds one entry per opened node: {first child slot << 4 | mask of the child slots in
+// use, mask of the lanes that opened it}; the (up to 4) siblings share the lane mask.  A round pops
+// up to TR_ENTRIES entries and gives each a group of 4 lanes: lane 4 e + i takes child slot i of the
+// e-th entry from the top (lanes whose slot is not in use sit the round out).  Every visited node pushes at most one
 // entry.  Above TR_HIGH entries the wave pops one entry per round: a depth-first descent then
 // adds at most 3 entries per tree level (< 32 levels), on top of what the last full round
 // pushed, so TR_STACK - TR_HIGH >= 4 TR_ENTRIES + 3 * 32 rules out an overflow.
@@ -1307,7 +1640,7 @@ static_assert(TR_ENTRIES >= 1 && TR_ENTRIES <= 16, "one group of 4 lanes per pop
 struct ForceArgs {
     const float4 *posm_s;
     const float4 *node_rec;
-    const uint2 *node_aux;   // x = first child << 3 | child count, y = float bits of the prune threshold
+    const uint2 *node_aux;   // x = first child slot << 4 | mask of the slots in use, y = float bits of the prune threshold
     const double *node_com;
     const uint32_t *idx;
     const uint32_t *tlist;   // may be null: targets are all sorted bodies
@@ -1431,8 +1764,8 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         bool have = false;
         if (grp < npop) {
             const uint32_t ew = snode[top - 1 - grp];
-            have = (uint32_t)sib < (ew & 7u);
-            u = (ew >> 3) + (uint32_t)sib;
+            have = (ew >> sib) & 1u;
+            u = (ew >> 4) + (uint32_t)sib;
             um = smask[top - 1 - grp];
         }
         const uint64_t cmask = __builtin_amdgcn_ballot_w64(have);  // lanes holding a node
@@ -1467,7 +1800,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
         const uint64_t nearm = cmask & ~(bodym | farm_all);
         if (openm != 0ull) {
             // one entry per opened node that has children
-            const uint64_t pushm = openm & __builtin_amdgcn_ballot_w64((aux.x & 7u) != 0u);
+            const uint64_t pushm = openm & __builtin_amdgcn_ballot_w64((aux.x & 15u) != 0u);
             if (__builtin_amdgcn_inverse_ballot_w64(pushm)) {
                 const int at = top + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pushm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushm, 0u));
                 snode[at] = aux.x;
@@ -1567,7 +1900,7 @@ __global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
                 om &= ~__builtin_amdgcn_ballot_w64(d2 < __uint_as_float(q.w));
             if (om != 0ull) {
                 const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
-                if ((packed & 7u) != 0u) {
+                if ((packed & 15u) != 0u) {
                     if (lane == 0) {
                         snode[top] = packed;
                         smask[top] = om;
@@ -1832,10 +2165,12 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 // Every device array of the pipeline for n bodies, taken from `alloc` (hipMalloc for a handle's
 // own buffers, a bump pointer for buffers carved out of a caller-provided arena).
 template <typename Alloc>
-static int bh_layout(BhBuffers &b, int n, Alloc &&alloc)
+static int bh_layout(BhBuffers &b, int n, bool with_pyramid, Alloc &&alloc)
 {
     b.n = n;
     b.node_cap = 2 * (size_t)n + 8;
+    if (with_pyramid && b.node_cap < PYR_CELLS)
+        b.node_cap = PYR_CELLS;  // the dense pyramid uses one node slot per cell
     b.sort_blocks = sort_blocks(n);
     NB_TRY(alloc(b.box, 4));
     NB_TRY(alloc(b.cut, 4));
@@ -1860,18 +2195,24 @@ static int bh_layout(BhBuffers &b, int n, Alloc &&alloc)
     NB_TRY(alloc(b.tcount, 4));
     NB_TRY(alloc(b.tblock, target_list_blocks(n)));
     NB_TRY(alloc(b.counters, 8));
+    if (with_pyramid) {
+        // first / one-past-last sorted body of every cell of the deepest pyramid level
+        NB_TRY(alloc(b.pc_range, (size_t)PYR_LEAF_CELLS));
+    }
     return NB_OK;
 }
 
 int bh_alloc(BhBuffers &b, int n)
 {
     b.owned = true;
-    NB_TRY(bh_layout(b, n, [](auto *&p, size_t count) { return dev_alloc(p, count); }));
+    NB_TRY(bh_layout(b, n, true, [](auto *&p, size_t count) { return dev_alloc(p, count); }));
     void *h = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
         return fail(NB_ERR_NOMEM, "hipHostMalloc failed");
     b.levels_host = (uint32_t *)h;
     *b.levels_host = 0u;
+    b.hint_host = b.levels_host + 1;
+    *b.hint_host = 0xffffffffu;  // key levels not known yet: bh_prime finds out
     return NB_OK;
 }
 
@@ -1885,7 +2226,7 @@ int bh_carve(BhBuffers &b, int n, void *base, size_t bytes, size_t *used)
     bool fits = true;
     b = BhBuffers();
     b.owned = false;
-    NB_TRY(bh_layout(b, n, [&](auto *&p, size_t count) {
+    NB_TRY(bh_layout(b, n, false, [&](auto *&p, size_t count) {
         using T = std::remove_reference_t<decltype(*p)>;
         const size_t need = (count * sizeof(T) + 256 + 255) & ~(size_t)255;
         if (base && off + need > bytes)
@@ -1929,6 +2270,7 @@ void bh_free(BhBuffers &b)
         (void)hipFree(b.tcount);
         (void)hipFree(b.tblock);
         (void)hipFree(b.counters);
+        (void)hipFree(b.pc_range);
         if (b.levels_host)
             (void)hipHostFree(b.levels_host);
     }

@@ -35,12 +35,35 @@ def exchange_bodies(sim, b):
 
 def tree_arrays(nb, sim):
     n = sim.n
-    cap = 2 * n + 8
+    cap = max(2 * n + 8, (4 ** 11 - 1) // 3)  # the dense pyramid has a node slot per cell of levels 0..10
     ls = sim.debug(nb.DBG_LEVEL_START, np.uint32, 64)
     rng = sim.debug(nb.DBG_NODE_RANGE, np.uint32, 2 * cap).reshape(-1, 2)
     ch = sim.debug(nb.DBG_NODE_CHILD, np.uint32, 2 * cap).reshape(-1, 2)
     com = sim.debug(nb.DBG_NODE_COM, np.float64, 4 * cap).reshape(-1, 4)
     return ls, rng, ch, com
+
+
+def walk_tree(rng, ch):
+    """Node slots reachable from the root (slot 0), their tree depth, and each one's children.
+    A node's children are the slots [first child, first child + child slots) that hold bodies: the
+    level-by-level tree packs children, the dense pyramid keeps a slot for each quadrant."""
+    nodes, depth, kids = [0], [0], {}
+    frontier = np.array([0], dtype=np.int64)
+    d = 0
+    while len(frontier):
+        cf = ch[frontier, 0].astype(np.int64)
+        nc = ch[frontier, 1].astype(np.int64)
+        cand = cf[:, None] + np.arange(4)[None, :]
+        ok = (np.arange(4)[None, :] < nc[:, None])
+        cand = np.where(ok, cand, 0)
+        ok &= rng[cand, 1] > 0
+        for u, row, okr in zip(frontier, cand, ok):
+            kids[int(u)] = row[okr]
+        frontier = cand[ok]
+        d += 1
+        nodes.extend(int(v) for v in frontier)
+        depth.extend([d] * len(frontier))
+    return np.array(nodes), np.array(depth), kids
 
 
 def cut_keys(nb, sim, ref_keys):
@@ -107,10 +130,11 @@ def test_tree_invariants_and_centre_of_mass(nb, name):
     keys = sim.debug(nb.DBG_SORTED_KEYS, np.uint64, n)
     idx = sim.debug(nb.DBG_SORTED_IDX, np.uint32, n)
     box = sim.debug(nb.DBG_BBOX, np.float64, 4)
-    nnodes = len(rng)
-    assert nnodes == ls.max() and nnodes <= 2 * n - 1
+    assert len(rng) == ls.max()
     assert rng[0, 0] == 0 and rng[0, 1] == n
-    leaves = ch[:, 1] == 0
+    nodes, depth, kids = walk_tree(rng, ch)
+    assert len(set(nodes.tolist())) == len(nodes) <= 2 * n - 1  # a tree: nobody is reached twice
+    leaves = np.array([u for u in nodes if len(kids[int(u)]) == 0])
     closed, levels = (int(v) for v in sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2))
     m = b["mass"][idx]
     p = b["pos"][idx]
@@ -120,7 +144,7 @@ def test_tree_invariants_and_centre_of_mass(nb, name):
     # centre of mass)
     assert rng[leaves, 1].sum() == n
     covered = np.zeros(n, dtype=int)
-    for u in np.flatnonzero(leaves):
+    for u in leaves:
         covered[rng[u, 0]:rng[u, 0] + rng[u, 1]] += 1
         if rng[u, 1] > 1:
             first, count = rng[u]
@@ -131,14 +155,15 @@ def test_tree_invariants_and_centre_of_mass(nb, name):
     assert np.all(covered == 1)
     if name == "collision_n4096":
         assert np.any(rng[leaves, 1] > 1)  # two discs of 2048 bodies: some share a level-9 cell
-    for u in range(nnodes):
+    for u in nodes:
         first, count = rng[u]
-        cf, nc = ch[u]
+        cr = rng[kids[int(u)]]
+        nc = len(cr)
         if nc == 0:
             continue
         assert 2 <= nc <= 4
+        assert np.all(kids[int(u)] > u)  # children live behind their parent
         # children tile the parent's range, in order
-        cr = rng[cf:cf + nc]
         assert cr[0, 0] == first and cr[-1, 0] + cr[-1, 1] == first + count
         assert np.all(cr[1:, 0] == cr[:-1, 0] + cr[:-1, 1])
         # the cell is the smallest one holding the range: keys share `lvl` digits, split at digit lvl
@@ -156,10 +181,6 @@ def test_tree_invariants_and_centre_of_mass(nb, name):
         assert com[u, 2] == pytest.approx(mm.sum(), rel=1e-12)
         assert com[u, 0] == pytest.approx((mm * p[first:first + count, 0]).sum() / mm.sum(), rel=1e-9, abs=1e-3)
         assert com[u, 1] == pytest.approx((mm * p[first:first + count, 1]).sum() / mm.sum(), rel=1e-9, abs=1e-3)
-    # levels are contiguous and children live one level below their parent
-    lv = np.searchsorted(ls[1:], np.arange(nnodes), side="right")
-    inner = np.flatnonzero(~leaves)
-    assert np.all(lv[ch[inner, 0]] == lv[inner] + 1)
     sim.close()
 
 
@@ -328,16 +349,20 @@ def test_two_rank_partition_equals_single_rank(nb, oracle):
 def test_tree_deeper_than_the_previous_steps(nb, oracle):
     """The per-level build kernels are launched for as many levels as earlier trees had; a tree
     that suddenly needs more levels (here: bodies on a coarse grid, then a sequence converging on
-    a point) must still be built completely and give the reference's accelerations."""
+    a point) must still be built completely and give the reference's accelerations.  With the
+    reference's constants the tree stops at level 8-9 and is built as a dense pyramid, which has no
+    such launches; a small opening angle (0.05) moves that level beyond what the pyramid covers."""
     n = 65
+    theta = 0.05
     wide = oracle.scenario(0, n, 12)
     g = np.arange(n - 1)
     wide["pos"][:-1, 0] = -4.0e11 + (g % 8) * 1.1e11 + 1.0e9 * np.sin(g)       # 8 x 8 grid, jittered
     wide["pos"][:-1, 1] = -4.0e11 + (g // 8) * 1.1e11 + 1.0e9 * np.cos(3 * g)
-    with nb.NBodySim(n, nb.BARNES_HUT) as sim:
+    with nb.NBodySim(n, nb.BARNES_HUT, nb.default_params(theta=theta)) as sim:
         sim.set_bodies(wide)
         sim.set_stage_timing(True)
         sim.update(3)
+        assert int(sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2)[1]) > 10  # the level-by-level build
         shallow = int(sim.debug(nb.DBG_COUNTERS, np.uint64, 8)[3])
         wide = sim.read_bodies()
         tight = wide.copy()
@@ -352,13 +377,37 @@ def test_tree_deeper_than_the_previous_steps(nb, oracle):
         acc = sim.compute_accel()
         deep = int(sim.debug(nb.DBG_COUNTERS, np.uint64, 8)[3])
         assert deep >= shallow + 4
-        ref = oracle.bh_accel(tight)
+        ref = oracle.bh_accel(tight, oracle.params(theta=theta))
         dyn = tight["is_dynamic"] != 0
         assert rel_err(acc[dyn], ref[dyn]).max() <= ACC_EXPECTED
         # and back to a shallow tree
         sim.set_bodies(wide)
         acc = sim.compute_accel()
-        assert rel_err(acc[dyn], oracle.bh_accel(wide)[dyn]).max() <= ACC_EXPECTED
+        assert rel_err(acc[dyn], oracle.bh_accel(wide, oracle.params(theta=theta))[dyn]).max() <= ACC_EXPECTED
+
+
+def test_keys_deeper_than_the_pyramid_fall_back(nb, oracle):
+    """The dense-pyramid kernels are launched when the previous steps' keys stopped at a level
+    they cover.  One body leaving at 1.6e8 m/s makes the bounding box five times wider within a step,
+    the level below which no cell is opened moves from 9 to beyond 10, and the step whose kernels
+    were already chosen must still build the complete tree (one block does); later steps use the
+    level-by-level build.  Every step's accelerations are the reference's (bar 1e-4: the float
+    coordinates now resolve a box five times the system's size)."""
+    n = 700
+    b = oracle.scenario(0, n, 31)
+    b["vel"][5] = (1.6e8, 0.8e8)
+    with nb.NBodySim(n, nb.BARNES_HUT) as sim:
+        sim.set_bodies(b)
+        depths = []
+        for step in range(4):
+            state = sim.read_bodies()
+            acc = sim.compute_accel()  # same kernels, same launch decisions as a step
+            depths.append(int(sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2)[1]))
+            ref = oracle.bh_accel(state)
+            dyn = state["is_dynamic"] != 0
+            assert rel_err(acc[dyn], ref[dyn]).max() <= ACC_TOL, step
+            sim.update(1)
+    assert depths[0] <= 10 < depths[1], depths
 
 
 @pytest.mark.parametrize("case", ["tiny_system", "wide_and_clump", "theta_small", "theta_large", "no_cutoff", "huge_cutoff"])
@@ -469,9 +518,9 @@ def test_spiral_50m_matches_the_reference_tree(nb, oracle, capsys):
               % (closed, cnt[2], cnt[3]), flush=True)
     assert np.all(np.isfinite(acc))
     assert 7 <= closed <= 10 and levels == closed
-    nnodes = int(cnt[2])
-    leaves = ch[:nnodes, 1] == 0
-    assert int(rng_[:nnodes][leaves, 1].sum()) == n
+    nodes, _, kids = walk_tree(rng_, ch)
+    leaves = np.array([u for u in nodes if len(kids[int(u)]) == 0])
+    assert int(rng_[leaves, 1].astype(np.int64).sum()) == n
     targets = sampled_targets(b, 256, 11)
     ref = oracle.bh_accel_list(b, targets)
     err = rel_err(acc[targets], ref)
