@@ -1134,10 +1134,9 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
 constexpr int LEAF_SHORT = 4;
 
 template <int NSUM, int STRIDE>
-__global__ __launch_bounds__(256) void k_leaf_finish(const uint32_t *chunk_info, int nchunks, double *leaf_sum)
+__device__ __forceinline__ void leaf_finish_chunk(const uint32_t *chunk_info, int nchunks, double *leaf_sum, const int c)
 {
     const int lane = lane_id();
-    const int c = blockIdx.x * 256 + threadIdx.x;
     const uint32_t mine = c < nchunks ? chunk_info[c] : (LEAF_NO_OWNER << 8);
     const bool own = (mine >> 8) != LEAF_NO_OWNER;
     double ps[NSUM], pr = 0.0;
@@ -1212,6 +1211,13 @@ __global__ __launch_bounds__(256) void k_leaf_finish(const uint32_t *chunk_info,
             t[NSUM] = fmax(t[NSUM], pr);
         }
     }
+}
+
+// Thread c of the grid takes chunk c (whole waves take consecutive chunks).
+template <int NSUM, int STRIDE>
+__global__ __launch_bounds__(256) void k_leaf_finish(const uint32_t *chunk_info, int nchunks, double *leaf_sum)
+{
+    leaf_finish_chunk<NSUM, STRIDE>(chunk_info, nchunks, leaf_sum, blockIdx.x * 256 + threadIdx.x);
 }
 
 int leaf_finish(hipStream_t s, const uint32_t *chunk_info, int n, double *leaf_sum, int dims)
@@ -1355,8 +1361,71 @@ __device__ __forceinline__ PyrCell pyr_load(const ComArgs &a, const uint4 *node_
     return c;
 }
 
-// The leaf of one cell of the last level (the arithmetic of com_level's leaf branch).
-__device__ __forceinline__ PyrCell pyr_leaf(const ComArgs &a, uint32_t first, uint32_t end, int level, double width0)
+// Sums {sum m x, sum m y, sum m, max radius} of the bodies [first, end) of one cell from the parts
+// the leaf pass left per 64-body chunk: the chunk where the run starts at the run's first position,
+// every later chunk in its own first slot.  The whole wave calls this (lanes without such a cell
+// pass end <= first + 1); a run over more than LEAF_SEQ chunks is summed by the wave together.
+// The order of the additions depends on the positions alone.
+constexpr uint32_t LEAF_SEQ = 8;
+
+__device__ __forceinline__ void pyr_leaf_sums(const double *leaf_sum, uint32_t first, uint32_t end, double (&out)[4])
+{
+    const bool multi = end > first + 1u;
+    const uint32_t c0 = first >> 6, cl = multi ? (end - 1u) >> 6 : c0;
+    const uint32_t extra = cl - c0;  // chunks after the first
+    if (multi) {
+        const double2 *p = (const double2 *)leaf_sum + 2 * (size_t)first;
+        const double2 u = p[0], v = p[1];
+        out[0] = u.x;
+        out[1] = u.y;
+        out[2] = v.x;
+        out[3] = v.y;
+        if (extra <= LEAF_SEQ)
+            for (uint32_t cc = c0 + 1u; cc <= cl; ++cc) {
+                const double2 *q = (const double2 *)leaf_sum + 2 * ((size_t)cc << 6);
+                const double2 uu = q[0], vv = q[1];
+                out[0] += uu.x;
+                out[1] += uu.y;
+                out[2] += vv.x;
+                out[3] = fmax(out[3], vv.y);
+            }
+    }
+    uint64_t longm = __builtin_amdgcn_ballot_w64(multi && extra > LEAF_SEQ);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (longm != 0ull) {
+        const int o = (int)__builtin_ctzll(longm);
+        longm &= longm - 1ull;
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)c0, o) + 1u;
+        const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)cl, o);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (uint32_t cc = b0 + lane; cc <= b1; cc += 64u) {
+            const double2 *q = (const double2 *)leaf_sum + 2 * ((size_t)cc << 6);
+            const double2 uu = q[0], vv = q[1];
+            s0 += uu.x;
+            s1 += uu.y;
+            s2 += vv.x;
+            s3 = fmax(s3, vv.y);
+        }
+#pragma unroll
+        for (int q = 32; q > 0; q >>= 1) {
+            s0 += __shfl_xor(s0, q);
+            s1 += __shfl_xor(s1, q);
+            s2 += __shfl_xor(s2, q);
+            s3 = fmax(s3, __shfl_xor(s3, q));
+        }
+        if ((int)lane == o) {
+            out[0] += s0;
+            out[1] += s1;
+            out[2] += s2;
+            out[3] = fmax(out[3], s3);
+        }
+    }
+}
+
+// The leaf of one cell of the last level (the arithmetic of com_level's leaf branch); sums: the
+// cell's pyr_leaf_sums when it holds several bodies.
+__device__ __forceinline__ PyrCell pyr_leaf(const ComArgs &a, uint32_t first, uint32_t end, int level, double width0,
+                                            const double (&sums)[4])
 {
     PyrCell c;
     c.first = first;
@@ -1379,11 +1448,9 @@ __device__ __forceinline__ PyrCell pyr_leaf(const ComArgs &a, uint32_t first, ui
             c.w = 0.0;
         }
     } else if (c.count > 1u) {
-        const double2 *ls = (const double2 *)a.leaf_sum + 2 * (size_t)first;
-        const double2 sxy = ls[0], smr = ls[1];
-        c.m = smr.x;
+        c.m = sums[2];
         float prune = -1.f;
-        multi_body_record(a, sxy.x, sxy.y, c.m, smr.y, width0, c.cx, c.cy, c.rec, c.w, prune);
+        multi_body_record(a, sums[0], sums[1], c.m, sums[3], width0, c.cx, c.cy, c.rec, c.w, prune);
         c.prune = __float_as_uint(prune);
     }
     return c;
@@ -1391,7 +1458,7 @@ __device__ __forceinline__ PyrCell pyr_leaf(const ComArgs &a, uint32_t first, ui
 
 // A cell from its four child cells (ch[0..3] = quadrants TL,TR,BL,BR; child_slot = slot of ch[0]):
 // updateCenterMass (quadtree.cpp:187-228) for a cell with bodies in several quadrants.
-__device__ __forceinline__ PyrCell pyr_combine(const ComArgs &a, const PyrCell (&ch)[4], uint32_t child_slot, int level,
+__device__ __forceinline__ PyrCell pyr_combine(const ComArgs &a, const PyrCell *ch, uint32_t child_slot, int level,
                                                double width0)
 {
     uint32_t mask = 0u, count = 0u, first = 0u;
@@ -1459,23 +1526,27 @@ __global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, co
     const uint32_t nroots = 1u << (2 * r), nleaf = 1u << (2 * sub);
     const double width0 = a.box[2] - a.box[0];
     for (uint32_t root = blockIdx.x; root < nroots; root += gridDim.x) {
-        for (uint32_t t = threadIdx.x; t < nleaf; t += 256) {
+        for (uint32_t t0 = 0; t0 < nleaf; t0 += 256) {  // whole waves go round: pyr_leaf_sums is a wave's work
+            const uint32_t t = t0 + threadIdx.x;
+            const bool mine = t < nleaf;
             const uint32_t c = root * nleaf + t;
-            const uint2 range = pc_range[c];
-            const PyrCell leaf = pyr_leaf(a, range.x, range.y, L, width0);
-            cells[pyr_offset(sub) + t] = leaf;
-            pyr_store(a, node_meta, pyr_offset(L) + c, leaf);
+            const uint2 range = mine ? pc_range[c] : make_uint2(0u, 0u);
+            double sums[4] = {0.0, 0.0, 0.0, 0.0};
+            pyr_leaf_sums(a.leaf_sum, range.x, range.y, sums);
+            if (mine) {
+                const PyrCell leaf = pyr_leaf(a, range.x, range.y, L, width0, sums);
+                cells[pyr_offset(sub) + t] = leaf;
+                pyr_store(a, node_meta, pyr_offset(L) + c, leaf);
+            }
         }
         __syncthreads();
         for (int k = sub - 1; k >= 0; --k) {
             const uint32_t cnt = 1u << (2 * k);
             for (uint32_t t = threadIdx.x; t < cnt; t += 256) {
-                PyrCell ch[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    ch[q] = cells[pyr_offset(k + 1) + 4 * t + q];
                 const uint32_t c = root * cnt + t;  // the cell's index within level r + k
-                const PyrCell me = pyr_combine(a, ch, pyr_offset(r + k + 1) + 4 * c, r + k, width0);
+                // (the children are read where they lie in LDS: a copy in registers would be indexed
+                // by the quadrant that holds the bodies, i.e. end up in scratch memory)
+                const PyrCell me = pyr_combine(a, &cells[pyr_offset(k + 1) + 4 * t], pyr_offset(r + k + 1) + 4 * c, r + k, width0);
                 cells[pyr_offset(k) + t] = me;
                 pyr_store(a, node_meta, pyr_offset(r + k) + c, me);
             }
@@ -1484,27 +1555,61 @@ __global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, co
     }
 }
 
-// Levels r - 1 .. 0 by one block, then the bookkeeping words.
-__global__ __launch_bounds__(1024) void k_pyr_top(ComArgs a, uint4 *node_meta, uint32_t *level_start,
-                                                  unsigned long long *counters)
+constexpr int COM_TOP_LEVELS = 5;  // levels 0..4: at most 341 cells
+
+// The last launch of the dense-pyramid build, one block.  Normally: levels r - 1 .. 0 of the
+// pyramid (in LDS), then the bookkeeping words.  When the keys of this step turned out deeper than
+// the pyramid kernels launched for it cover (cut[3] == 0: the device decides, the host only knew
+// the previous steps) the same block builds the whole level-by-level tree and its centres of mass
+// instead: slow, complete, and rare -- the host learns the new depth from this very step.
+__global__ __launch_bounds__(256) void k_pyr_top(ComArgs a, uint4 *node_meta, uint32_t *level_start,
+                                                 unsigned long long *counters, const uint64_t *keys, Split<2> *split,
+                                                 uint32_t *bsum, int n, uint32_t *levels_host, const uint32_t *chunk_info)
 {
-    if (a.cut[3] == 0u)
-        return;
     __shared__ PyrCell cells[PYR_LDS_CELLS];  // levels 0..r
+    if (a.cut[3] == 0u) {
+        // (the pyramid sums the leaf pass's per-chunk parts itself; this build wants them finished)
+        const int nchunks = (n + 63) / 64;
+        for (int base = 0; base < nchunks; base += 256)
+            leaf_finish_chunk<3, 4>(chunk_info, nchunks, const_cast<double *>(a.leaf_sum), base + (int)threadIdx.x);
+        build_init(node_meta, level_start, n, counters);
+        int levels = 0;
+        for (int d = 0; d < BH_MAX_DEPTH - 2; ++d) {
+            __threadfence_block();
+            __syncthreads();  // level_start[d + 1] and the level's nodes are written
+            if (level_start[d + 1] == level_start[d])
+                break;  // uniform
+            levels = d + 1;
+            build_count<2>(keys, node_meta, split, level_start, bsum, d);
+            __threadfence_block();
+            __syncthreads();  // bsum[0] and the splits are written
+            build_emit<2>(node_meta, split, level_start, bsum, d);
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            counters[2] = level_start[levels];
+            counters[3] = (unsigned long long)levels;
+            if (levels_host)
+                *levels_host = (uint32_t)levels;
+        }
+        for (int dd = levels - 1; dd >= 0; --dd) {
+            com_level(a, dd);
+            __threadfence_block();
+            __syncthreads();
+        }
+        return;
+    }
     const int L = (int)a.cut[1];
     const int r = pyr_split(L);
     const double width0 = a.box[2] - a.box[0];
-    for (uint32_t c = threadIdx.x; c < (1u << (2 * r)); c += 1024)
+    for (uint32_t c = threadIdx.x; c < (1u << (2 * r)); c += 256)
         cells[pyr_offset(r) + c] = pyr_load(a, node_meta, pyr_offset(r) + c);
     __syncthreads();
     for (int l = r - 1; l >= 0; --l) {
         const uint32_t cnt = 1u << (2 * l);
-        for (uint32_t c = threadIdx.x; c < cnt; c += 1024) {
-            PyrCell ch[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                ch[q] = cells[pyr_offset(l + 1) + 4 * c + q];
-            const PyrCell me = pyr_combine(a, ch, pyr_offset(l + 1) + 4 * c, l, width0);
+        for (uint32_t c = threadIdx.x; c < cnt; c += 256) {
+            const PyrCell me = pyr_combine(a, &cells[pyr_offset(l + 1) + 4 * c], pyr_offset(l + 1) + 4 * c, l, width0);
             cells[pyr_offset(l) + c] = me;
             pyr_store(a, node_meta, pyr_offset(l) + c, me);
         }
@@ -1516,46 +1621,6 @@ __global__ __launch_bounds__(1024) void k_pyr_top(ComArgs a, uint4 *node_meta, u
     if (threadIdx.x < 8)
         counters[threadIdx.x] = threadIdx.x == 2 ? (unsigned long long)pyr_offset(L + 1)
                                                  : (threadIdx.x == 3 ? (unsigned long long)(L + 1) : 0ull);
-}
-
-constexpr int COM_TOP_LEVELS = 5;  // levels 0..4: at most 341 cells
-
-// The whole level-by-level tree and its centres of mass by ONE block in one launch, for a step
-// whose kernels were launched for the dense pyramid but whose keys turned out deeper than it
-// covers (cut[3] == 0); returns at once otherwise.  Slow, complete, and rare: the host learns the
-// new depth from this very step.
-__global__ __launch_bounds__(256) void k_tree_fallback(ComArgs a, const uint64_t *keys, uint4 *node_meta, Split<2> *split,
-                                                       uint32_t *level_start, uint32_t *bsum, int n,
-                                                       unsigned long long *counters, uint32_t *levels_host)
-{
-    if (a.cut[3] != 0u)
-        return;
-    build_init(node_meta, level_start, n, counters);
-    int levels = 0;
-    for (int d = 0; d < BH_MAX_DEPTH - 2; ++d) {
-        __threadfence_block();
-        __syncthreads();  // level_start[d + 1] and the level's nodes are written
-        if (level_start[d + 1] == level_start[d])
-            break;  // uniform
-        levels = d + 1;
-        build_count<2>(keys, node_meta, split, level_start, bsum, d);
-        __threadfence_block();
-        __syncthreads();  // bsum[0] and the splits are written
-        build_emit<2>(node_meta, split, level_start, bsum, d);
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        counters[2] = level_start[levels];
-        counters[3] = (unsigned long long)levels;
-        if (levels_host)
-            *levels_host = (uint32_t)levels;
-    }
-    for (int dd = levels - 1; dd >= 0; --dd) {
-        com_level(a, dd);
-        __threadfence_block();
-        __syncthreads();
-    }
 }
 
 int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
@@ -1581,23 +1646,20 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.bucket = a.bucket_depth > 0 ? 1 : 0;
     hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[b.sorted], b.idx[b.sorted], a.n, a.pos,
                        a.mass, a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum, b.chunk_info, b.cut, b.pc_range);
-    NB_TRY(leaf_finish(s, b.chunk_info, a.n, b.leaf_sum, 2));
     if (b.use_pyr) {
-        // Two launches build the tree, the centres of mass and the traversal records.  Should the
-        // keys of this very step go deeper than the pyramid covers (the device decides; the host
-        // only knew the previous steps), these kernels return at once and one block each of the
-        // level-by-level build and centre-of-mass kernels does the step instead: slower, complete.
+        // Two launches build the tree, the centres of mass and the traversal records (k_pyr_top also
+        // holds the one-block fallback for keys deeper than these launches cover).
         const dim3 grid(1u << (2 * pyr_split(b.pyr_levels)));
         if (b.pyr_levels > PYR_SMALL_LEVEL)
             hipLaunchKernelGGL(k_pyr_sub<PYR_LDS_CELLS>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range);
         else
             hipLaunchKernelGGL(k_pyr_sub<341>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range);
-        hipLaunchKernelGGL(k_pyr_top, dim3(1), dim3(1024), 0, s, c, b.node_meta, b.level_start, b.counters);
-        hipLaunchKernelGGL(k_tree_fallback, dim3(1), dim3(256), 0, s, c, b.keys[b.sorted], b.node_meta, (Split<2> *)b.split,
-                           b.level_start, b.bsum, a.n, b.counters, b.levels_host);
+        hipLaunchKernelGGL(k_pyr_top, dim3(1), dim3(256), 0, s, c, b.node_meta, b.level_start, b.counters, b.keys[b.sorted],
+                           (Split<2> *)b.split, b.bsum, a.n, b.levels_host, b.chunk_info);
         NB_HIP(hipGetLastError());
         return NB_OK;
     }
+    NB_TRY(leaf_finish(s, b.chunk_info, a.n, b.leaf_sum, 2));
     // levels beyond the ones the build launched per-level kernels for: one block, one launch
     if (b.launched < BH_MAX_DEPTH - 1)
         hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, b.launched, BH_MAX_DEPTH - 1);
