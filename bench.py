@@ -56,8 +56,10 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
-def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=True, params=None):
-    """Returns (seconds for `steps` steps, max over ranks; mean per-stage ms of this rank)."""
+def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=True, params=None, late_at=0):
+    """Returns (seconds for `steps` steps, max over ranks; mean per-stage ms of this rank; traversal
+    counters of rank 0; and, with late_at > 0, the same timing repeated once the run has reached
+    step late_at: {"ms_per_step", "stage_ms", "at_step"})."""
     from nbody_amd.distributed import DistributedSim, GpuEngine
 
     sim = nb.NBodySim(len(bodies), alg, params)
@@ -102,8 +104,27 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
                     "batches": int(c[6]), "max_stack": int(c[7])}
     elif alg == nb.BARNES_HUT and world > 1:
         step()  # keep the ranks' collectives matched with rank 0's extra step
+    late = None
+    done = warmup + steps + (1 if alg == nb.BARNES_HUT else 0)
+    if late_at > done:
+        sim.set_stage_timing(False, counters=False)
+        for _ in range(late_at - done):
+            step()
+        sim.set_stage_timing(stage_timing, counters=False)
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier_sync(world)
+        ldt = time.perf_counter() - t0
+        lstages = sim.stage_ms() if stage_timing else {}
+        if world > 1:
+            t = torch.tensor([ldt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ldt = float(t.item())
+        late = {"at_step": late_at, "ms_per_step": ldt * 1e3 / steps, "stage_ms": lstages}
     sim.close()
-    return dt, stages, counters
+    return dt, stages, counters, late
 
 
 def three_d_leg(nb, bh_n, direct_n, steps, warmup):
@@ -145,46 +166,60 @@ def three_d_leg(nb, bh_n, direct_n, steps, warmup):
 
 
 def cpu_baseline(nb, bh_n):
-    """The reference's CPU Barnes-Hut (its own classes when the prebuilt library is present,
-    else the plain-C port) on a bounded sample: one step of the same scenario at a smaller N."""
+    """The reference's own CPU Barnes-Hut (its classes, compiled unmodified into oracle/_ref; the
+    plain-C port when that library is absent) timed on this host: ONE real step of the workload's
+    scenario at N = 1,000,000, single thread (the reference has no threading) -- nothing
+    extrapolated in `value`.  Beside it: the port on all the host cores this job may use (OpenMP over
+    the targets of the traversal), the N log N projection to the workload's N, and the CPU direct
+    sum."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, Reference
 
-    sample_n = 400000
+    sample_n = min(1000000, bh_n)
     b = nb.init_scenario(nb.COLLISION, sample_n, 12345)
+    orc = Oracle()
     if Reference.available():
         ref = Reference()
         kind = "reference"
         t0 = time.perf_counter()
         ref.step(1, b, 1)
         dt = time.perf_counter() - t0
-        td = None
-        bd = nb.init_scenario(nb.SPIRAL, 16384, 12345)
-        t0 = time.perf_counter()
-        ref.step(0, bd, 1)
-        td = time.perf_counter() - t0
     else:
-        orc = Oracle()
         kind = "port"
         t0 = time.perf_counter()
         orc.bh_step(b, 1)
         dt = time.perf_counter() - t0
-        bd = nb.init_scenario(nb.SPIRAL, 16384, 12345)
-        t0 = time.perf_counter()
-        orc.direct_step(bd, 1)
-        td = time.perf_counter() - t0
+    # all cores: the share of the machine this job has (OMP_NUM_THREADS on the GPU box), not nproc
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or len(os.sched_getaffinity(0))
+    cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+    orc.set_threads(cores)
+    t0 = time.perf_counter()
+    orc.bh_step(b, 1)
+    dt_all = time.perf_counter() - t0
+    bd = nb.init_scenario(nb.SPIRAL, 16384, 12345)
+    t0 = time.perf_counter()
+    orc.direct_step(bd, 1)
+    td_all = time.perf_counter() - t0
+    orc.set_threads(1)
+    t0 = time.perf_counter()
+    (ref.step(0, bd, 1) if kind == "reference" else orc.direct_step(bd, 1))
+    td = time.perf_counter() - t0
     scale = (bh_n * math.log2(bh_n)) / (sample_n * math.log2(sample_n))
     return {
         "value": dt * 1e3,
         "unit": "ms/step at N=%d" % sample_n,
         "cores": 1,
         "kind": kind,
-        "sample": "1 step of the reference CPU BarnesHut::update, galaxy collision N=%d (same generator and "
-                  "seed as the workload, 8%% of its bodies), single thread (the reference has no threading)" % sample_n,
-        "scaled_to_workload_ms": dt * 1e3 * scale,
-        "scaling_rule": "N log2 N",
+        "sample": "1 step of the reference CPU BarnesHut::update, galaxy collision N=%d (the workload's generator and "
+                  "seed), single thread; measured, not extrapolated" % sample_n,
+        "projected_to_workload_ms": dt * 1e3 * scale,
+        "projection_rule": "N log2 N from N=%d to N=%d" % (sample_n, bh_n),
+        "all_cores": {"value": dt_all * 1e3, "unit": "ms/step at N=%d" % sample_n, "cores": cores, "kind": "port",
+                      "note": "plain-C port of the reference (oracle/), OpenMP over the traversal's targets; the tree "
+                              "build stays on one thread as in the reference"},
         "direct_sum_ginteractions_per_s": 16384.0 * 16384.0 / td / 1e9,
-        "direct_sum_sample": "1 step of the reference CPU DirectSum::update, spiral N=16384",
+        "direct_sum_all_cores_ginteractions_per_s": 16384.0 * 16384.0 / td_all / 1e9,
+        "direct_sum_sample": "1 step of the CPU DirectSum::update, spiral N=16384",
         "host_cpus": os.cpu_count(),
     }
 
@@ -214,6 +249,9 @@ def main():
     ap.add_argument("--direct-n", type=int, default=1000000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-direct", action="store_true", help="skip the direct-sum half of the metric")
+    ap.add_argument("--no-50m", action="store_true", help="skip the Barnes-Hut N = 50M leg (BASELINE.json configs[4])")
+    ap.add_argument("--big-n", type=int, default=50000000)
+    ap.add_argument("--late-step", type=int, default=300, help="also time the headline run from this step on (0: no)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -243,15 +281,34 @@ def main():
             dist.init_process_group("nccl", device_id=device)
     nb = load_package()
 
+    # the ranks RCCL really connected: every rank contributes its number to an all-gather
+    rccl_ranks = 1
+    if world > 1:
+        mine = torch.tensor([rank], dtype=torch.int64, device=device if not rehearsal else "cpu")
+        seen = torch.empty(world, dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(seen, mine)
+        rccl_ranks = int(torch.unique(seen).numel())
+        assert rccl_ranks == dist.get_world_size() == world
+
     # ---- headline: Barnes-Hut, galaxy collision N = 5M ----
     bodies = nb.init_scenario(nb.COLLISION, args.bh_n, 12345)
-    dt, stages, counters = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device)
+    dt, stages, counters, late = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device,
+                                           late_at=args.late_step)
     ms_per_step = dt * 1e3 / args.steps
     # the same workload on the tree of the reference's GPU program (depth-9 cap, leaves as point
     # masses): the configuration the published 1509 ms was measured with
-    gdt, gstages, gcounters = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device,
-                                        params=nb.default_params(bucket_depth=9))
+    gdt, gstages, gcounters, _ = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device,
+                                           params=nb.default_params(bucket_depth=9))
     del bodies
+
+    # ---- BASELINE.json configs[4]: Barnes-Hut, spiral galaxy N = 50M (on 1..8 GPUs) ----
+    big = None
+    if not args.no_50m:
+        bodies = nb.init_scenario(nb.SPIRAL, args.big_n, 12345)
+        bdt, bstages, bcounters, _ = timed_run(nb, nb.BARNES_HUT, bodies, max(3, args.steps // 2), 2, rank, world, device)
+        del bodies
+        big = {"n": args.big_n, "scenario": "spiral", "ms_per_step": bdt * 1e3 / max(3, args.steps // 2),
+               "stage_ms": bstages, "tree": bcounters}
 
     # ---- second half of the metric: direct-sum G interactions/s ----
     direct = None
@@ -262,7 +319,7 @@ def main():
         # this leg warms up for 30 steps and times 40
         for n, steps, warm in ((65536, max(args.steps, 40), 30), (args.direct_n, 3, 1)):
             b = nb.init_scenario(nb.SPIRAL, n, 12345)
-            ddt, dstages, _ = timed_run(nb, nb.DIRECT, b, steps, warm, rank, world, device)
+            ddt, dstages, _, _ = timed_run(nb, nb.DIRECT, b, steps, warm, rank, world, device)
             gi = float(n) * n * steps / ddt / 1e9
             kern_ms = dstages.get("force", 0.0)
             entry = {"n": n, "steps": steps, "ms_per_step": ddt * 1e3 / steps, "ginteractions_per_s": gi,
@@ -294,7 +351,10 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "kernel": "k_bh_force", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": force_ms,
-                "algorithmic_bytes_per_launch": alg_bytes}
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic_source": "profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of this kernel from separate "
+                                  "rocprofv3 --pmc passes over `bench.py --steps 2 --warmup 1` (steps 2-3 of this "
+                                  "workload), not measured in this run"}
     if counters and force_ms > 0:
         roofline["body_node_interactions_per_s"] = counters["accepted_interactions"] / (force_ms * 1e-3)
         roofline["node_evaluations_per_s"] = counters["node_evaluations"] / (force_ms * 1e-3)
@@ -310,6 +370,7 @@ def main():
         "value": ms_per_step,
         "unit": "ms/step",
         "n_gpus": world,
+        "rccl_ranks": rccl_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
@@ -322,11 +383,14 @@ def main():
             "workload": "galaxy collision N=%d Barnes-Hut theta=0.5, 2-D (BASELINE.json configs[3]); forces FP32, "
                         "state and integration FP64" % args.bh_n,
             "scenario_seed": 12345,
-            "parallelism": "targets split over %d GPU(s), tree rebuilt on every GPU, all-gather of positions" % world,
+            "parallelism": "targets split over %d GPU(s), tree rebuilt on every GPU, one in-place ncclAllGather of "
+                           "positions per step issued by the library on its own stream" % world,
         },
         "speedup_vs_published": PUBLISHED_MS / ms_per_step,
         "stage_ms": stages,
         "tree": counters,
+        "late_state": late,
+        "barnes_hut_50m": big,
         "gpu_tree_mode": {"ms_per_step": gdt * 1e3 / args.steps, "bucket_depth": 9, "stage_ms": gstages, "tree": gcounters,
                           "speedup_vs_published": PUBLISHED_MS / (gdt * 1e3 / args.steps),
                           "note": "nb_params.bucket_depth = 9: the reference GPU program's tree (cells not split below "

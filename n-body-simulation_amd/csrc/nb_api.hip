@@ -52,6 +52,7 @@ BhStepArgs bh_args(nb_sim *s, int do_integrate)
     a.pos = s->pos;
     a.mass = s->mass;
     a.radius = s->radius;
+    a.mass_radius = s->mass_radius;
     a.dyn = s->dyn;
     a.vel = s->vel;
     a.acc = s->acc;
@@ -202,6 +203,7 @@ void release(nb_sim *s)
     (void)hipFree(s->acc);
     (void)hipFree(s->mass);
     (void)hipFree(s->radius);
+    (void)hipFree(s->mass_radius);
     (void)hipFree(s->dyn);
     (void)hipFree(s->order_d);
     (void)hipFree(s->posm[0]);
@@ -290,6 +292,7 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
         chk(dev_alloc(s->part, s->part_cap));
         chk(dev_alloc(s->ds_meta, direct_meta_bytes(n)));
     } else {
+        chk(dev_alloc(s->mass_radius, s->cap));
         chk(bh_alloc(s->bh, n));
     }
     if (rc == NB_OK)
@@ -352,6 +355,12 @@ static int load_bodies(nb_sim *s, const nb_body *b, int n)
     NB_HIP(hipMemcpy(s->radius, radius.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(s->dyn, dyn.data(), n, hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(s->order_d, s->order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    if (s->alg == NB_ALG_BARNES_HUT) {
+        std::vector<double2> mr(n);
+        for (int k = 0; k < n; ++k)
+            mr[k] = make_double2(mass[k], radius[k]);
+        NB_HIP(hipMemcpy(s->mass_radius, mr.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+    }
     if (s->alg == NB_ALG_DIRECT) {
         s->cur = 0;
         NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, n, 0, n, s->units, s->p.collision_th, s->posm[0], s->rad_s));

@@ -68,6 +68,7 @@ struct BhStepArgs {
     const double2 *pos;
     const double *mass;
     const double *radius;
+    const double2 *mass_radius;  // {mass, radius} per body: the same values, gathered together
     const uint8_t *dyn;
     double2 *vel;
     double2 *acc;

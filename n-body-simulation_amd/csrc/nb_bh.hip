@@ -32,7 +32,6 @@ namespace nb {
 // children of a cell are the consecutive slots pyr_offset(l + 1) + 4 c .. + 3 and nothing has to be
 // numbered or searched for.
 constexpr int PYR_MAX_LEVEL = 10;
-constexpr int PYR_SMALL_LEVEL = 9;  // deepest level the small-LDS variant of k_pyr_sub covers
 __host__ __device__ constexpr uint32_t pyr_offset(int l) { return (uint32_t)((((uint64_t)1 << (2 * l)) - 1) / 3); }
 constexpr uint32_t PYR_CELLS = pyr_offset(PYR_MAX_LEVEL + 1);        // cells of all levels
 constexpr uint32_t PYR_LEAF_CELLS = 1u << (2 * PYR_MAX_LEVEL);        // cells of the deepest level
@@ -170,9 +169,7 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     // finished step stopped at a level it covers
     const uint32_t hint = (b.pc_range && b.hint_host) ? *(volatile const uint32_t *)b.hint_host : 0xffffffffu;
     b.use_pyr = hint <= (uint32_t)PYR_MAX_LEVEL;
-    // the deepest key level the pyramid kernels of this step can do (the variant with the small LDS
-    // footprint when the keys of the previous steps fit it)
-    b.pyr_levels = !b.use_pyr ? -1 : (hint <= (uint32_t)PYR_SMALL_LEVEL ? PYR_SMALL_LEVEL : PYR_MAX_LEVEL);
+    b.pyr_levels = b.use_pyr ? PYR_MAX_LEVEL : -1;  // the deepest key level the pyramid kernels can do
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, a.bucket_depth,
                        a.theta, a.collision_th, b.box, b.cut, b.pyr_levels, b.hint_host);
     NB_HIP(hipGetLastError());
@@ -931,8 +928,7 @@ struct ComArgs {
     const uint32_t *level_start;
     const uint32_t *idx;
     const double2 *pos;
-    const double *mass;
-    const double *radius;
+    const double2 *mass_radius;
     const float4 *posm_s;
     const double *box;
     double *node_com;
@@ -1011,7 +1007,7 @@ __device__ __forceinline__ void store_node(const ComArgs &a, uint32_t u, const u
 // The same pass writes every body's float record {x, y, m, radius} in sorted order (the
 // traversal's targets and the one-body leaves), since it reads exactly what that needs.
 __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const uint32_t *idx, int n, const double2 *pos,
-                                                   const double *mass, const double *radius, const double *box,
+                                                   const double2 *mass_radius, const double *box,
                                                    double inv_len, double inv_mass, float4 *posm_s, double *leaf_sum,
                                                    uint32_t *chunk_info, const uint32_t *cut, uint2 *pc_range)
 {
@@ -1028,10 +1024,11 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
     if (valid) {
         const uint32_t o = idx[k];
         const double2 p = pos[o];
-        sm = mass[o];
+        const double2 mr = mass_radius[o];  // one 16-byte gather for the two constants of a body
+        sm = mr.x;
         sx = p.x * sm;
         sy = p.y * sm;
-        rm = radius[o];
+        rm = mr.y;
         posm_s[k] = make_float4((float)((p.x - ox) * inv_len), (float)((p.y - oy) * inv_len), (float)(sm * inv_mass),
                                 (float)(rm * inv_len));
     }
@@ -1252,10 +1249,11 @@ __device__ __forceinline__ void com_level(const ComArgs &a, int d)
                 const double2 p = a.pos[o];
                 cx = p.x;
                 cy = p.y;
-                mtot = a.mass[o];
+                const double2 mr = a.mass_radius[o];
+                mtot = mr.x;
                 const float4 pm = a.posm_s[first];
-                rec = make_float4(pm.x, pm.y, pm.z, -(float)((a.radius[o] + a.cth) * a.inv_len));
-                width = -a.radius[o];
+                rec = make_float4(pm.x, pm.y, pm.z, -(float)((mr.y + a.cth) * a.inv_len));
+                width = -mr.y;
                 if (a.bucket) {
                     rec.w = 0.f;  // see multi_body_record; the target's own leaf (distance 0) is
                     width = 0.0;  // "opened" and has no children
@@ -1323,12 +1321,14 @@ struct PyrCell {
     float4 rec;           // node_rec
     uint32_t child, prune;  // node_aux: first child slot << 4 | quadrant mask, prune threshold bits
     uint32_t first, count;  // bodies (sorted positions)
-    uint32_t mchild, mlevel;  // node_meta z, w: first child slot, child slots | cell level << 8
 };
+static_assert(sizeof(PyrCell) == 64, "LDS budget of the pyramid kernels");
 
 __device__ __forceinline__ void pyr_store(const ComArgs &a, uint4 *node_meta, uint32_t slot, const PyrCell &c)
 {
-    node_meta[slot] = make_uint4(c.first, c.count, c.mchild, c.mlevel);
+    // (node_meta is what nb_debug_read shows: body range, first child slot, child slots)
+    const bool inner = c.count != 0u && (c.child & 15u) != 0u;
+    node_meta[slot] = make_uint4(c.first, c.count, inner ? c.child >> 4 : 0u, inner ? 4u : 0u);
     if (c.count == 0u)
         return;
     double2 *o = (double2 *)a.node_com + 2 * (size_t)slot;
@@ -1344,8 +1344,6 @@ __device__ __forceinline__ PyrCell pyr_load(const ComArgs &a, const uint4 *node_
     const uint4 meta = node_meta[slot];
     c.first = meta.x;
     c.count = meta.y;
-    c.mchild = meta.z;
-    c.mlevel = meta.w;
     if (c.count != 0u) {
         const double2 *o = (const double2 *)a.node_com + 2 * (size_t)slot;
         const double2 xy = o[0], mw = o[1];
@@ -1363,63 +1361,77 @@ __device__ __forceinline__ PyrCell pyr_load(const ComArgs &a, const uint4 *node_
 
 // Sums {sum m x, sum m y, sum m, max radius} of the bodies [first, end) of one cell from the parts
 // the leaf pass left per 64-body chunk: the chunk where the run starts at the run's first position,
-// every later chunk in its own first slot.  The whole wave calls this (lanes without such a cell
-// pass end <= first + 1); a run over more than LEAF_SEQ chunks is summed by the wave together.
-// The order of the additions depends on the positions alone.
+// every later chunk in its own first slot.  A thread adds up to LEAF_SEQ later chunks itself
+// (leaves of ~130 bodies are the rule); a longer run -- the core of a collapsed disc puts tens of
+// thousands of bodies into one cell -- is left to pyr_long_sums.  The order of the additions
+// depends on the positions alone.
 constexpr uint32_t LEAF_SEQ = 8;
 
-__device__ __forceinline__ void pyr_leaf_sums(const double *leaf_sum, uint32_t first, uint32_t end, double (&out)[4])
+__device__ __forceinline__ bool pyr_short_sums(const double *leaf_sum, uint32_t first, uint32_t end, double (&out)[4])
 {
-    const bool multi = end > first + 1u;
-    const uint32_t c0 = first >> 6, cl = multi ? (end - 1u) >> 6 : c0;
-    const uint32_t extra = cl - c0;  // chunks after the first
-    if (multi) {
-        const double2 *p = (const double2 *)leaf_sum + 2 * (size_t)first;
-        const double2 u = p[0], v = p[1];
-        out[0] = u.x;
-        out[1] = u.y;
-        out[2] = v.x;
-        out[3] = v.y;
-        if (extra <= LEAF_SEQ)
-            for (uint32_t cc = c0 + 1u; cc <= cl; ++cc) {
+    if (end <= first + 1u)
+        return false;
+    const uint32_t c0 = first >> 6, cl = (end - 1u) >> 6;
+    const double2 *p = (const double2 *)leaf_sum + 2 * (size_t)first;
+    const double2 u = p[0], v = p[1];
+    out[0] = u.x;
+    out[1] = u.y;
+    out[2] = v.x;
+    out[3] = v.y;
+    if (cl - c0 > LEAF_SEQ)
+        return true;  // the later chunks are still to be added
+    for (uint32_t cc = c0 + 1u; cc <= cl; ++cc) {
+        const double2 *q = (const double2 *)leaf_sum + 2 * ((size_t)cc << 6);
+        const double2 uu = q[0], vv = q[1];
+        out[0] += uu.x;
+        out[1] += uu.y;
+        out[2] += vv.x;
+        out[3] = fmax(out[3], vv.y);
+    }
+    return false;
+}
+
+// The later chunks of one long run, by a whole wave: 256 chunks a round, four loads in flight per lane.
+__device__ __forceinline__ void pyr_long_sums(const double *leaf_sum, uint32_t first, uint32_t end, double (&out)[4])
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b0 = (first >> 6) + 1u, b1 = (end - 1u) >> 6;
+    double s[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        s[i][0] = s[i][1] = s[i][2] = s[i][3] = 0.0;
+    for (uint32_t base = b0 + lane; base <= b1; base += 256u) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t cc = base + 64u * (uint32_t)i;
+            if (cc <= b1) {
                 const double2 *q = (const double2 *)leaf_sum + 2 * ((size_t)cc << 6);
                 const double2 uu = q[0], vv = q[1];
-                out[0] += uu.x;
-                out[1] += uu.y;
-                out[2] += vv.x;
-                out[3] = fmax(out[3], vv.y);
+                s[i][0] += uu.x;
+                s[i][1] += uu.y;
+                s[i][2] += vv.x;
+                s[i][3] = fmax(s[i][3], vv.y);
             }
-    }
-    uint64_t longm = __builtin_amdgcn_ballot_w64(multi && extra > LEAF_SEQ);
-    const uint32_t lane = threadIdx.x & 63u;
-    while (longm != 0ull) {
-        const int o = (int)__builtin_ctzll(longm);
-        longm &= longm - 1ull;
-        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)c0, o) + 1u;
-        const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)cl, o);
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (uint32_t cc = b0 + lane; cc <= b1; cc += 64u) {
-            const double2 *q = (const double2 *)leaf_sum + 2 * ((size_t)cc << 6);
-            const double2 uu = q[0], vv = q[1];
-            s0 += uu.x;
-            s1 += uu.y;
-            s2 += vv.x;
-            s3 = fmax(s3, vv.y);
         }
+    }
 #pragma unroll
-        for (int q = 32; q > 0; q >>= 1) {
-            s0 += __shfl_xor(s0, q);
-            s1 += __shfl_xor(s1, q);
-            s2 += __shfl_xor(s2, q);
-            s3 = fmax(s3, __shfl_xor(s3, q));
-        }
-        if ((int)lane == o) {
-            out[0] += s0;
-            out[1] += s1;
-            out[2] += s2;
-            out[3] = fmax(out[3], s3);
-        }
+    for (int i = 1; i < 4; ++i) {
+        s[0][0] += s[i][0];
+        s[0][1] += s[i][1];
+        s[0][2] += s[i][2];
+        s[0][3] = fmax(s[0][3], s[i][3]);
     }
+#pragma unroll
+    for (int q = 32; q > 0; q >>= 1) {
+        s[0][0] += __shfl_xor(s[0][0], q);
+        s[0][1] += __shfl_xor(s[0][1], q);
+        s[0][2] += __shfl_xor(s[0][2], q);
+        s[0][3] = fmax(s[0][3], __shfl_xor(s[0][3], q));
+    }
+    out[0] = s[0][0];
+    out[1] = s[0][1];
+    out[2] = s[0][2];
+    out[3] = s[0][3];
 }
 
 // The leaf of one cell of the last level (the arithmetic of com_level's leaf branch); sums: the
@@ -1432,17 +1444,16 @@ __device__ __forceinline__ PyrCell pyr_leaf(const ComArgs &a, uint32_t first, ui
     c.count = end > first ? end - first : 0u;
     c.child = 0u;
     c.prune = __float_as_uint(-1.f);
-    c.mchild = 0u;
-    c.mlevel = (uint32_t)level << 8;
     if (c.count == 1u) {
         const uint32_t o = a.idx[first];
         const double2 p = a.pos[o];
         c.cx = p.x;
         c.cy = p.y;
-        c.m = a.mass[o];
+        const double2 mr = a.mass_radius[o];
+        c.m = mr.x;
         const float4 pm = a.posm_s[first];
-        c.rec = make_float4(pm.x, pm.y, pm.z, -(float)((a.radius[o] + a.cth) * a.inv_len));
-        c.w = -a.radius[o];
+        c.rec = make_float4(pm.x, pm.y, pm.z, -(float)((mr.y + a.cth) * a.inv_len));
+        c.w = -mr.y;
         if (a.bucket) {
             c.rec.w = 0.f;
             c.w = 0.0;
@@ -1479,8 +1490,6 @@ __device__ __forceinline__ PyrCell pyr_combine(const ComArgs &a, const PyrCell *
     c.count = count;
     c.child = 0u;
     c.prune = __float_as_uint(-1.f);
-    c.mchild = 0u;
-    c.mlevel = (uint32_t)level << 8;
     if (nch == 0)
         return c;
     double sx = 0.0, sy = 0.0, mtot = 0.0;
@@ -1498,42 +1507,69 @@ __device__ __forceinline__ PyrCell pyr_combine(const ComArgs &a, const PyrCell *
     cell_record(a, c.cx, c.cy, mtot, level, width0, c.rec, c.w, prune);
     c.prune = __float_as_uint(prune);
     c.child = (child_slot << 4) | mask;
-    c.mchild = child_slot;
-    c.mlevel = 4u | ((uint32_t)level << 8);
     return c;
 }
 
 // The pyramid is cut at level r = pyr_split(L): k_pyr_sub gives every cell of level r a block that
-// builds levels r..L under it bottom-up in LDS; k_pyr_top then builds levels r-1..0 in one block,
-// also in LDS (<= 1024 cells of level r come in, one load each).  Both hold at most 1365 cells.
-__host__ __device__ constexpr int pyr_split(int L) { return L > 5 ? 5 : (L > 4 ? L - 4 : 0); }
-constexpr int PYR_LDS_CELLS = 1365;  // 1 + 4 + 16 + 64 + 256 + 1024
-static_assert(PYR_MAX_LEVEL - pyr_split(PYR_MAX_LEVEL) <= 5 && pyr_split(PYR_MAX_LEVEL) <= 5, "LDS holds six levels");
+// builds levels r..L under it bottom-up in LDS (at most 4 levels below the block's cell: 341
+// cells); k_pyr_top then builds levels r-1..0 in one block, also in LDS.
+__host__ __device__ constexpr int pyr_split(int L) { return L > 4 ? L - 4 : 0; }
+constexpr int PYR_SUB_CELLS = 341;   // 1 + 4 + 16 + 64 + 256
+constexpr int PYR_TOP_CELLS = 1365;  // levels 0..5 ...
+constexpr int PYR_TOP_STAGE = 512;   // ... and, when r = 6, the level-6 cells in batches of this many
+static_assert(pyr_split(PYR_MAX_LEVEL) <= 6, "k_pyr_top stages at most one level beyond the six it holds");
 
-// Levels r .. L: one block per cell of level r.  CELLS: what the block's LDS holds -- 341 cells are
-// enough for L <= 9 (at most four levels under the block's cell), L = 10 needs 1365; the host picks
-// the variant from the depth of the previous steps' keys and tells k_bbox_final the deepest level
-// that variant can do (deeper keys fall back to the level-by-level build).
-template <int CELLS>
+// Levels r .. L: one block per cell of level r.
 __global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, const uint2 *pc_range)
 {
     if (a.cut[3] == 0u)
         return;
-    __shared__ PyrCell cells[CELLS];  // levels r..L of the block's cell
+    __shared__ PyrCell cells[PYR_SUB_CELLS];  // levels r..L of the block's cell
+    __shared__ uint4 long_range[256];   // cells whose bodies span many chunks: first, end, owning thread
+    __shared__ double long_sum[256][4];
+    __shared__ int nlong;
     const int L = (int)a.cut[1];
     const int r = pyr_split(L);
     const int sub = L - r;
     const uint32_t nroots = 1u << (2 * r), nleaf = 1u << (2 * sub);
     const double width0 = a.box[2] - a.box[0];
     for (uint32_t root = blockIdx.x; root < nroots; root += gridDim.x) {
-        for (uint32_t t0 = 0; t0 < nleaf; t0 += 256) {  // whole waves go round: pyr_leaf_sums is a wave's work
+        for (uint32_t t0 = 0; t0 < nleaf; t0 += 256) {
             const uint32_t t = t0 + threadIdx.x;
             const bool mine = t < nleaf;
             const uint32_t c = root * nleaf + t;
             const uint2 range = mine ? pc_range[c] : make_uint2(0u, 0u);
             double sums[4] = {0.0, 0.0, 0.0, 0.0};
-            pyr_leaf_sums(a.leaf_sum, range.x, range.y, sums);
+            // long runs are dealt to the block's four waves (they cluster in a few neighbouring
+            // cells, i.e. in one wave's threads)
+            if (threadIdx.x == 0)
+                nlong = 0;
+            __syncthreads();
+            if (pyr_short_sums(a.leaf_sum, range.x, range.y, sums)) {
+                const int at = atomicAdd(&nlong, 1);
+                long_range[at] = make_uint4(range.x, range.y, threadIdx.x, 0u);
+            }
+            __syncthreads();
+            for (int i = (int)(threadIdx.x >> 6); i < nlong; i += 4) {
+                const uint4 lr = long_range[i];
+                double extra[4];
+                pyr_long_sums(a.leaf_sum, lr.x, lr.y, extra);
+                if ((threadIdx.x & 63u) == 0u) {
+                    long_sum[lr.z][0] = extra[0];
+                    long_sum[lr.z][1] = extra[1];
+                    long_sum[lr.z][2] = extra[2];
+                    long_sum[lr.z][3] = extra[3];
+                }
+            }
+            __syncthreads();
             if (mine) {
+                const uint32_t c0 = range.x >> 6, cl = range.y > range.x + 1u ? (range.y - 1u) >> 6 : c0;
+                if (cl - c0 > LEAF_SEQ) {
+                    sums[0] += long_sum[threadIdx.x][0];
+                    sums[1] += long_sum[threadIdx.x][1];
+                    sums[2] += long_sum[threadIdx.x][2];
+                    sums[3] = fmax(sums[3], long_sum[threadIdx.x][3]);
+                }
                 const PyrCell leaf = pyr_leaf(a, range.x, range.y, L, width0, sums);
                 cells[pyr_offset(sub) + t] = leaf;
                 pyr_store(a, node_meta, pyr_offset(L) + c, leaf);
@@ -1566,7 +1602,7 @@ __global__ __launch_bounds__(256) void k_pyr_top(ComArgs a, uint4 *node_meta, ui
                                                  unsigned long long *counters, const uint64_t *keys, Split<2> *split,
                                                  uint32_t *bsum, int n, uint32_t *levels_host, const uint32_t *chunk_info)
 {
-    __shared__ PyrCell cells[PYR_LDS_CELLS];  // levels 0..r
+    __shared__ PyrCell cells[PYR_TOP_CELLS + PYR_TOP_STAGE];  // levels 0..min(r, 5), then the staging area
     if (a.cut[3] == 0u) {
         // (the pyramid sums the leaf pass's per-chunk parts itself; this build wants them finished)
         const int nchunks = (n + 63) / 64;
@@ -1603,10 +1639,29 @@ __global__ __launch_bounds__(256) void k_pyr_top(ComArgs a, uint4 *node_meta, ui
     const int L = (int)a.cut[1];
     const int r = pyr_split(L);
     const double width0 = a.box[2] - a.box[0];
-    for (uint32_t c = threadIdx.x; c < (1u << (2 * r)); c += 256)
-        cells[pyr_offset(r) + c] = pyr_load(a, node_meta, pyr_offset(r) + c);
-    __syncthreads();
-    for (int l = r - 1; l >= 0; --l) {
+    int held = r;  // the level held in LDS from which the sweep goes on
+    if (r > 5) {
+        // level 6 does not fit: it passes through the staging area, 512 cells (128 parents) at a time
+        PyrCell *stage = cells + PYR_TOP_CELLS;
+        for (uint32_t base = 0; base < (1u << (2 * r)); base += PYR_TOP_STAGE) {
+            for (uint32_t c = threadIdx.x; c < PYR_TOP_STAGE; c += 256)
+                stage[c] = pyr_load(a, node_meta, pyr_offset(r) + base + c);
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < PYR_TOP_STAGE / 4; j += 256) {
+                const uint32_t c = base / 4 + j;  // the parent's index within level r - 1
+                const PyrCell me = pyr_combine(a, &stage[4 * j], pyr_offset(r) + 4 * c, r - 1, width0);
+                cells[pyr_offset(r - 1) + c] = me;
+                pyr_store(a, node_meta, pyr_offset(r - 1) + c, me);
+            }
+            __syncthreads();
+        }
+        held = r - 1;
+    } else {
+        for (uint32_t c = threadIdx.x; c < (1u << (2 * r)); c += 256)
+            cells[pyr_offset(r) + c] = pyr_load(a, node_meta, pyr_offset(r) + c);
+        __syncthreads();
+    }
+    for (int l = held - 1; l >= 0; --l) {
         const uint32_t cnt = 1u << (2 * l);
         for (uint32_t c = threadIdx.x; c < cnt; c += 256) {
             const PyrCell me = pyr_combine(a, &cells[pyr_offset(l + 1) + 4 * c], pyr_offset(l + 1) + 4 * c, l, width0);
@@ -1630,8 +1685,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.level_start = b.level_start;
     c.idx = b.idx[b.sorted];
     c.pos = a.pos;
-    c.mass = a.mass;
-    c.radius = a.radius;
+    c.mass_radius = a.mass_radius;
     c.posm_s = b.posm_s;
     c.box = b.box;
     c.node_com = b.node_com;
@@ -1645,15 +1699,15 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     c.cth = a.collision_th;
     c.bucket = a.bucket_depth > 0 ? 1 : 0;
     hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[b.sorted], b.idx[b.sorted], a.n, a.pos,
-                       a.mass, a.radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum, b.chunk_info, b.cut, b.pc_range);
+                       a.mass_radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum, b.chunk_info, b.cut, b.pc_range);
     if (b.use_pyr) {
         // Two launches build the tree, the centres of mass and the traversal records (k_pyr_top also
         // holds the one-block fallback for keys deeper than these launches cover).
-        const dim3 grid(1u << (2 * pyr_split(b.pyr_levels)));
-        if (b.pyr_levels > PYR_SMALL_LEVEL)
-            hipLaunchKernelGGL(k_pyr_sub<PYR_LDS_CELLS>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range);
-        else
-            hipLaunchKernelGGL(k_pyr_sub<341>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range);
+        // one block per cell of the split level of the previous steps' keys (blocks go round if this
+        // step's keys are deeper)
+        const uint32_t hint = *(volatile const uint32_t *)b.hint_host;
+        const dim3 grid(1u << (2 * pyr_split((int)(hint <= (uint32_t)PYR_MAX_LEVEL ? hint : (uint32_t)PYR_MAX_LEVEL))));
+        hipLaunchKernelGGL(k_pyr_sub, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range);
         hipLaunchKernelGGL(k_pyr_top, dim3(1), dim3(256), 0, s, c, b.node_meta, b.level_start, b.counters, b.keys[b.sorted],
                            (Split<2> *)b.split, b.bsum, a.n, b.levels_host, b.chunk_info);
         NB_HIP(hipGetLastError());

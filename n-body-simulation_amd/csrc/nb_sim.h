@@ -28,6 +28,7 @@ struct nb_sim {
     double2 *pos = nullptr, *vel = nullptr, *acc = nullptr;
     double2 *pos2 = nullptr;  // direct sum: the other FP64 position buffer (pos is the current one)
     double *mass = nullptr, *radius = nullptr;
+    double2 *mass_radius = nullptr;  // Barnes-Hut: {mass, radius} per body (one gather instead of two)
     uint8_t *dyn = nullptr;
     float4 *posm[2] = {nullptr, nullptr};
     float *rad_s = nullptr;

@@ -7,10 +7,11 @@ committed summaries:
     profiles/<round>_pmc.json             per-kernel averages of the counter passes
     profiles/traffic.json                 HBM bytes per launch of the dominant kernels (read by bench.py)
 
-HBM bytes follow MI355X_MICROARCH.md's HBM section: FETCH_SIZE and WRITE_SIZE are in KiB; on
-gfx950 FETCH_SIZE reports half the bytes of a wide coalesced 16 B/lane stream.  The traversal's
-loads are 16 B/lane gathers whose calibration is unknown, so both the raw and the doubled figure
-are stored and the raw one is used as `traffic` (a lower bound).
+HBM bytes follow MI355X_MICROARCH.md's HBM section: FETCH_SIZE and WRITE_SIZE are in KiB, from
+separate --pmc passes; on gfx950 FETCH_SIZE reports half the bytes of 16 B/lane loads, so it is
+doubled; WRITE_SIZE is taken as it is.  `traffic` = 2 x FETCH_SIZE + WRITE_SIZE per launch (the
+traversal's loads are 16 B/lane gathers and 8 B/lane loads: the doubling is exact for the former
+and an upper estimate for the latter; the raw figure is kept beside it).
 """
 import collections
 import csv
@@ -30,7 +31,7 @@ def short(name):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
     out = os.path.join(ROOT, "profiles")
     stats = max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
@@ -55,12 +56,12 @@ def main():
             fetch = summary[k]["FETCH_SIZE"]["mean"] * 1024
             write = summary[k]["WRITE_SIZE"]["mean"] * 1024
             traffic[tag] = {
-                "hbm_bytes_per_launch": fetch + write,
+                "hbm_bytes_per_launch": 2 * fetch + write,
                 "fetch_bytes_raw": fetch,
-                "fetch_bytes_if_halved_by_counter": 2 * fetch,
+                "fetch_bytes_doubled": 2 * fetch,
                 "write_bytes": write,
                 "l2_hit_rate": summary[k].get("l2_hit_rate"),
-                "workload": "galaxy collision N=5,000,000 (bench.py default)",
+                "workload": "galaxy collision N=5,000,000, steps 2-3 after the bodies are set (bench.py --steps 2 --warmup 1)",
                 "round": rnd,
             }
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1, sort_keys=True)

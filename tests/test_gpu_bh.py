@@ -386,6 +386,26 @@ def test_tree_deeper_than_the_previous_steps(nb, oracle):
         assert rel_err(acc[dyn], oracle.bh_accel(wide, oracle.params(theta=theta))[dyn]).max() <= ACC_EXPECTED
 
 
+@pytest.mark.parametrize("stretch,level", [(1.6, 10), (0.6, 8), (0.3, 7)])
+def test_pyramid_levels_other_than_nine(nb, oracle, stretch, level):
+    """The reference's scenarios close the tree at level 9; a wider or narrower system moves that
+    level (10 is the deepest the dense pyramid covers: its top kernel then stages one level more
+    than it holds).  A clump of bodies inside one closed cell makes a leaf that spans many 64-body
+    chunks, whose sums the pyramid kernel adds up wave by wave."""
+    n = 6000
+    b = oracle.scenario(0, n, 9)
+    b["pos"] *= stretch
+    rng_ = np.random.default_rng(3)
+    b["pos"][100:2100] = b["pos"][100] + rng_.uniform(-1.0e8, 1.0e8, size=(2000, 2))
+    sim, acc = run_accel(nb, b)
+    closed, levels = (int(v) for v in sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2))
+    sim.close()
+    assert closed == levels == level
+    ref = oracle.bh_accel(b)
+    dyn = b["is_dynamic"] != 0
+    assert rel_err(acc[dyn], ref[dyn]).max() <= ACC_EXPECTED
+
+
 def test_keys_deeper_than_the_pyramid_fall_back(nb, oracle):
     """The dense-pyramid kernels are launched when the previous steps' keys stopped at a level
     they cover.  One body leaving at 1.6e8 m/s makes the bounding box five times wider within a step,
