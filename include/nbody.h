@@ -212,13 +212,19 @@ int nb_set_stage_timing(nb_sim *sim, int on);
 int nb_stage_ms(nb_sim *sim, float *out, int count);
 
 /* Re-derives the exchange order (see NB_DBG_ORDER) from the current positions and re-sorts the
- * device state by it, through the host.  Nothing the caller sees changes (nb_read_bodies keeps
- * returning bodies in the caller's order; results differ only by the rounding of a different
- * summation order); it restores the speed of long direct-sum runs, whose kernel relies on
- * neighbouring indices being neighbours in space.  nb_step does it by itself for the direct sum
- * every max(64, min(4096, 5e7 / n)) steps.  Not for partitioned simulations.  The reference keeps
- * bodies in creation order and has nothing of the kind. */
+ * device state by it, on the device and asynchronously on the simulation's stream (a bounding box,
+ * a radix sort of Morton codes, one gather per per-body array).  Nothing the caller sees changes
+ * (nb_read_bodies keeps returning bodies in the caller's order; results differ only by the
+ * rounding of a different summation order); it restores the speed of long direct-sum runs, whose
+ * kernel relies on neighbouring slots being neighbours in space.  nb_step and nb_step_distributed
+ * do it by themselves for the direct sum every max(64, min(4096, 5e7 / n)) steps.  The reference
+ * keeps bodies in creation order and has nothing of the kind.
+ * A partitioned simulation driven through nb_step_local / nb_step_finish may call it between
+ * steps on EVERY rank, after all-gathering the velocity buffer the way the position buffer is
+ * gathered (nb_velocity_buffer: same layout): every rank then derives the same order, and the
+ * slots a rank owns afterwards hold bodies whose velocities other ranks kept so far. */
 int nb_refresh_order(nb_sim *sim);
+int nb_velocity_buffer(nb_sim *sim, void **device_ptr, size_t *chunk_records, size_t *record_bytes);
 
 /* Conserved quantities of the current state, computed in FP64 (not part of the hot path):
  * out[0] total mass, [1..2] centre of mass, [3..4] momentum, [5] angular momentum about the
@@ -300,6 +306,8 @@ int nb3_set_partition(nb_sim3 *sim, int rank, int world);
 int nb3_exchange_buffer(nb_sim3 *sim, void **device_ptr, size_t *chunk_records, size_t *record_bytes);
 int nb3_step_local(nb_sim3 *sim);
 int nb3_step_finish(nb_sim3 *sim);
+int nb3_refresh_order(nb_sim3 *sim);
+int nb3_velocity_buffer(nb_sim3 *sim, void **device_ptr, size_t *chunk_records, size_t *record_bytes);
 int nb3_comm_init(nb_sim3 *sim, int rank, int world, const void *id); /* id: from nb_comm_unique_id */
 int nb3_step_distributed(nb_sim3 *sim, int nsteps);
 /* `which` is an nb_debug_array.  Differences from nb_debug_read: NB_DBG_BBOX is 6 doubles

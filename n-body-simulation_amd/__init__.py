@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "nb_step", "nb_compute_accel", "nb_read_bodies", "nb_sync", "nb_set_stream", "nb_set_partition",
     "nb_exchange_buffer", "nb_step_local", "nb_step_finish", "nb_debug_read", "nb_set_stage_timing",
     "nb_stage_ms", "nb_diagnostics", "nb_refresh_order", "nb_compute_accel_static", "nb_comm_unique_id", "nb_comm_init", "nb_step_distributed",
-    "nb3_comm_init", "nb3_step_distributed", "nb_last_error", "nb_version",
+    "nb_velocity_buffer", "nb3_comm_init", "nb3_step_distributed", "nb3_refresh_order", "nb3_velocity_buffer", "nb_last_error", "nb_version",
     "nb3_init_scenario", "nb3_create", "nb3_destroy", "nb3_setup", "nb3_set_bodies", "nb3_step",
     "nb3_compute_accel", "nb3_read_bodies", "nb3_sync", "nb3_debug_read", "nb3_set_stage_timing", "nb3_stage_ms",
     "nb3_diagnostics", "nb3_set_stream", "nb3_set_partition", "nb3_exchange_buffer", "nb3_step_local", "nb3_step_finish",
@@ -125,6 +125,9 @@ def load_library(path=None):
     lib.nb_comm_unique_id.argtypes = [vp, C.c_size_t]
     lib.nb_comm_init.argtypes = [vp, i, i, vp]
     lib.nb_step_distributed.argtypes = [vp, i]
+    lib.nb_velocity_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.nb3_velocity_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.nb3_refresh_order.argtypes = [vp]
     lib.nb3_comm_init.argtypes = [vp, i, i, vp]
     lib.nb3_step_distributed.argtypes = [vp, i]
     lib.nb3_init_scenario.argtypes = [i, i, u, C.c_double, vp]
@@ -241,6 +244,13 @@ class NBodySim:
         _check(self._lib.nb_exchange_buffer(self._h, C.byref(p), C.byref(c), C.byref(r)))
         return p.value, c.value, r.value
 
+    def velocity_buffer(self):
+        """(device pointer, records per rank, bytes per record) of the velocity array, laid out like the
+        exchange buffer (all-gathered before a partitioned simulation renews its order)."""
+        p, c, r = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _check(self._lib.nb_velocity_buffer(self._h, C.byref(p), C.byref(c), C.byref(r)))
+        return p.value, c.value, r.value
+
     def step_local(self):
         _check(self._lib.nb_step_local(self._h))
 
@@ -341,6 +351,14 @@ class NBodySim3:
         p, c, r = C.c_void_p(), C.c_size_t(), C.c_size_t()
         _check(self._lib.nb3_exchange_buffer(self._h, C.byref(p), C.byref(c), C.byref(r)))
         return p.value, c.value, r.value
+
+    def velocity_buffer(self):
+        p, c, r = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _check(self._lib.nb3_velocity_buffer(self._h, C.byref(p), C.byref(c), C.byref(r)))
+        return p.value, c.value, r.value
+
+    def refresh_order(self):
+        _check(self._lib.nb3_refresh_order(self._h))
 
     def step_local(self):
         _check(self._lib.nb3_step_local(self._h))

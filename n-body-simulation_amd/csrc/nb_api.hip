@@ -148,6 +148,15 @@ void exchange_order(const nb_body *b, int n, std::vector<uint32_t> &order)
 
 void mark(nb_sim *s, int k) { s->timer.mark(s->stream, k); }
 
+// Direct sum: its run-against-wave box tests rely on slot ranges being compact patches of space;
+// bodies wander, so the order is renewed now and then.  Steps between two renewals: they cost a
+// few passes over the per-body arrays, well below 1 % of the steps between at this interval.
+long refresh_interval(int n)
+{
+    const long interval = 50000000L / (n > 0 ? n : 1);
+    return interval < 64 ? 64 : (interval > 4096 ? 4096 : interval);
+}
+
 int step_local(nb_sim *s, int do_integrate)
 {
     if (s->alg == NB_ALG_DIRECT) {
@@ -212,6 +221,7 @@ void release(nb_sim *s)
     (void)hipFree(s->part);
     (void)hipFree(s->ds_meta);
     bh_free(s->bh);
+    refresh_free(s->rb);
     comm_destroy(s->comm);
     s->comm = nullptr;
     s->timer.destroy();
@@ -291,6 +301,7 @@ int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
         s->part_cap = (size_t)s->jsplit * n;
         chk(dev_alloc(s->part, s->part_cap));
         chk(dev_alloc(s->ds_meta, direct_meta_bytes(n)));
+        chk(refresh_alloc(s->rb, n));  // nb_step renews the order by itself for the direct sum
     } else {
         chk(dev_alloc(s->mass_radius, s->cap));
         chk(bh_alloc(s->bh, n));
@@ -355,6 +366,7 @@ static int load_bodies(nb_sim *s, const nb_body *b, int n)
     NB_HIP(hipMemcpy(s->radius, radius.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(s->dyn, dyn.data(), n, hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(s->order_d, s->order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    s->order_stale = false;
     if (s->alg == NB_ALG_BARNES_HUT) {
         std::vector<double2> mr(n);
         for (int k = 0; k < n; ++k)
@@ -393,31 +405,49 @@ int nb_set_bodies(nb_sim *s, const nb_body *b, int n)
     return NB_OK;
 }
 
-// The device state as it is (no leapfrog synchronisation), in the caller's order.
-static int read_raw(nb_sim *s, std::vector<nb_body> &out)
+// The slot -> caller index map on the host (fetched again after the device renewed it).
+static int host_order(nb_sim *s)
 {
-    const int n = s->n;
-    std::vector<double2> pos(n), vel(n), acc(n);
-    std::vector<double> mass(n), radius(n);
-    std::vector<uint8_t> dyn(n);
+    if (!s->order_stale)
+        return NB_OK;
     NB_HIP(hipStreamSynchronize(s->stream));
-    NB_HIP(hipMemcpy(pos.data(), s->pos, sizeof(double2) * n, hipMemcpyDeviceToHost));
-    NB_HIP(hipMemcpy(vel.data(), s->vel, sizeof(double2) * n, hipMemcpyDeviceToHost));
-    NB_HIP(hipMemcpy(acc.data(), s->acc, sizeof(double2) * n, hipMemcpyDeviceToHost));
-    NB_HIP(hipMemcpy(mass.data(), s->mass, sizeof(double) * n, hipMemcpyDeviceToHost));
-    NB_HIP(hipMemcpy(radius.data(), s->radius, sizeof(double) * n, hipMemcpyDeviceToHost));
-    NB_HIP(hipMemcpy(dyn.data(), s->dyn, n, hipMemcpyDeviceToHost));
-    out.resize(n);
-    for (int k = 0; k < n; ++k) {
-        nb_body &x = out[s->order[k]];
-        std::memset(&x, 0, sizeof(x));
-        x.is_dynamic = dyn[k];
-        x.mass = mass[k];
-        x.radius = radius[k];
-        x.position = {pos[k].x, pos[k].y};
-        x.velocity = {vel[k].x, vel[k].y};
-        x.acceleration = {acc[k].x, acc[k].y};
+    NB_HIP(hipMemcpy(s->order.data(), s->order_d, sizeof(uint32_t) * s->n, hipMemcpyDeviceToHost));
+    s->order_stale = false;
+    return NB_OK;
+}
+
+// Renews the exchange order on the device, everything enqueued on the stream (nb_refresh.h): new
+// order from the current positions, every per-body array gathered into it, the direct sum's
+// records packed again.  The float records' origin moves to the middle of the box the PREVIOUS
+// renewal saw (the device leaves it in host-visible memory; the host never waits for it), so a
+// drifting system keeps its precision.
+static int device_refresh(nb_sim *s)
+{
+    if (s->rb.n != s->n)
+        NB_TRY(refresh_alloc(s->rb, s->n));
+    if (s->rb.origin_set && s->alg == NB_ALG_DIRECT) {
+        s->units.origin[0] = ((volatile double *)s->rb.origin_host)[0];
+        s->units.origin[1] = ((volatile double *)s->rb.origin_host)[1];
     }
+    NB_TRY(refresh_sort(s->stream, s->rb, (const double *)s->pos, 2, s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->pos, sizeof(double2), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->vel, sizeof(double2), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->acc, sizeof(double2), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->mass, sizeof(double), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->radius, sizeof(double), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->mass_radius, sizeof(double2), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->dyn, 1, s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->order_d, sizeof(uint32_t), s->n));
+    s->order_stale = true;
+    if (s->alg == NB_ALG_DIRECT) {
+        s->cur = 0;
+        NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, s->n, 0, s->n, s->units, s->p.collision_th, s->posm[0],
+                         s->rad_s));
+        NB_TRY(pad_posm(s->stream, s->posm[0], s->n));
+        NB_HIP(hipMemcpyAsync(s->posm[1], s->posm[0], sizeof(float4) * direct_record_floats4(s->n), hipMemcpyDeviceToDevice,
+                              s->stream));
+    }
+    s->steps_in_order = 0;
     return NB_OK;
 }
 
@@ -429,12 +459,18 @@ int nb_refresh_order(nb_sim *s)
         return fail(NB_ERR_STATE, "nb_refresh_order: no bodies were set");
     if (s->mid_step)
         return fail(NB_ERR_STATE, "nb_refresh_order: a split step is in flight");
-    if (s->world != 1)
-        return fail(NB_ERR_STATE, "nb_refresh_order: a partitioned simulation holds other ranks' velocities only as "
-                                  "they were when the bodies were set; re-inject the gathered state instead");
-    std::vector<nb_body> b;
-    NB_TRY(read_raw(s, b));
-    return load_bodies(s, b.data(), s->n);
+    // (a partitioned simulation: the caller has all-gathered the velocity buffer, see nbody.h)
+    return device_refresh(s);
+}
+
+int nb_velocity_buffer(nb_sim *s, void **device_ptr, size_t *chunk_records, size_t *record_bytes)
+{
+    if (!s || !device_ptr || !chunk_records || !record_bytes)
+        return fail(NB_ERR_ARG, "nb_velocity_buffer: NULL argument");
+    *device_ptr = s->vel;
+    *chunk_records = s->chunk;
+    *record_bytes = sizeof(double2);
+    return NB_OK;
 }
 
 int nb_setup(nb_sim *s, int scenario, unsigned seed)
@@ -484,17 +520,13 @@ int nb_step(nb_sim *s, int nsteps)
         return fail(NB_ERR_STATE, "nb_step: a partitioned simulation steps with nb_step_local / nb_step_finish");
     if (s->mid_step)
         return fail(NB_ERR_STATE, "nb_step: a split step is in flight");
-    // Direct sum: its run-against-block tests rely on index ranges being compact patches of space;
-    // bodies wander, so the order is renewed now and then.  The interval keeps the cost of doing
-    // so (a round trip through the host, ~0.2 us per body) below ~2 % of the steps between.
-    long interval = 50000000L / (s->n > 0 ? s->n : 1);
-    interval = interval < 64 ? 64 : (interval > 4096 ? 4096 : interval);
+    const long interval = refresh_interval(s->n);
     for (int k = 0; k < nsteps; ++k) {
         NB_TRY(step_local(s, 1));
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
         if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= interval)
-            NB_TRY(nb_refresh_order(s));
+            NB_TRY(device_refresh(s));
     }
     return NB_OK;
 }
@@ -542,6 +574,13 @@ int nb_step_distributed(nb_sim *s, int nsteps)
         mark(s, s->alg == NB_ALG_DIRECT ? 2 : 7);
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
+        if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= refresh_interval(s->n)) {
+            // every rank renews the order from the same positions; the new slices hold bodies other
+            // ranks advanced so far, whose velocities come with one more all-gather
+            if (s->world > 1)
+                NB_TRY(comm_all_gather_f64(s->comm, (double *)s->vel, 2 * s->chunk, s->stream));
+            NB_TRY(device_refresh(s));
+        }
     }
     return NB_OK;
 }
@@ -588,6 +627,7 @@ int nb_read_bodies(nb_sim *s, nb_body *out)
         NB_TRY(rc);
     }
     NB_HIP(hipStreamSynchronize(s->stream));
+    NB_TRY(host_order(s));
     NB_HIP(hipMemcpy(pos.data(), s->pos, sizeof(double2) * n, hipMemcpyDeviceToHost));
     NB_HIP(hipMemcpy(vel.data(), s->vel, sizeof(double2) * n, hipMemcpyDeviceToHost));
     NB_HIP(hipMemcpy(acc.data(), s->acc, sizeof(double2) * n, hipMemcpyDeviceToHost));
@@ -732,6 +772,7 @@ int nb_debug_read(nb_sim *s, int which, void *out, size_t bytes, size_t *written
         need = sizeof(uint32_t) * s->n;
         if (bytes < need)
             return fail(NB_ERR_ARG, "nb_debug_read: buffer too small");
+        NB_TRY(host_order(s));
         std::memcpy(out, s->order.data(), need);
         if (written)
             *written = need;

@@ -10,6 +10,7 @@
 #include "nb_bh.h"
 #include "nb_comm.h"
 #include "nb_common.h"
+#include "nb_refresh.h"
 #include "nb_timing.h"
 #include "nb_dim3.h"
 
@@ -33,6 +34,9 @@ struct nb_sim3 {
     double *mass = nullptr, *radius = nullptr;
     uint8_t *dyn = nullptr;
     std::vector<uint32_t> order;  // caller index of the body in each slot
+    uint32_t *order_d = nullptr;  // the same on the device
+    bool order_stale = false;     // the device renewed the order; `order` is fetched when next needed
+    RefreshBuffers rb;            // buffers of the renewal (made at nb3_create for the direct sum, else on first use)
 
     // partition: this process integrates slots [t0, t1)
     int rank = 0, world = 1;
@@ -222,6 +226,8 @@ void release(nb_sim3 *s)
     (void)hipFree(s->ds.part);
     (void)hipFree(s->ds.meta);
     bh3_free(s->bh);
+    (void)hipFree(s->order_d);
+    refresh_free(s->rb);
     comm_destroy(s->comm);
     s->comm = nullptr;
     s->timer.destroy();
@@ -257,6 +263,8 @@ int load_bodies(nb_sim3 *s, const nb_body3 *b, int n)
     NB_HIP(hipMemcpy(s->mass, mass.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(s->radius, radius.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(s->dyn, dyn.data(), n, hipMemcpyHostToDevice));
+    NB_HIP(hipMemcpy(s->order_d, s->order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    s->order_stale = false;
     if (s->alg == NB_ALG_DIRECT) {
         s->ds.cur = 0;
         NB_TRY(pack_posm3(s->stream, s->pos, s->mass, s->radius, n, s->units, s->p.collision_th, s->ds.posm[0], s->ds.wcut,
@@ -270,6 +278,53 @@ int load_bodies(nb_sim3 *s, const nb_body3 *b, int n)
     return NB_OK;
 }
 
+// The slot -> caller index map on the host (fetched again after the device renewed it).
+int host_order(nb_sim3 *s)
+{
+    if (!s->order_stale)
+        return NB_OK;
+    NB_HIP(hipStreamSynchronize(s->stream));
+    NB_HIP(hipMemcpy(s->order.data(), s->order_d, sizeof(uint32_t) * s->n, hipMemcpyDeviceToHost));
+    s->order_stale = false;
+    return NB_OK;
+}
+
+long refresh_interval(int n)
+{
+    const long interval = 50000000L / (n > 0 ? n : 1);
+    return interval < 64 ? 64 : (interval > 4096 ? 4096 : interval);
+}
+
+// Renews the order on the device, asynchronously on the stream (nb_refresh.h; the 2-D handle does
+// the same): new order from the current positions, every per-body array gathered into it, the
+// direct sum's records packed again relative to the middle of the box the previous renewal saw.
+int device_refresh(nb_sim3 *s)
+{
+    if (s->rb.n != s->n)
+        NB_TRY(refresh_alloc(s->rb, s->n));
+    if (s->rb.origin_set && s->alg == NB_ALG_DIRECT)
+        for (int d = 0; d < 3; ++d)
+            s->units.origin[d] = ((volatile double *)s->rb.origin_host)[d];
+    NB_TRY(refresh_sort(s->stream, s->rb, s->pos, 3, s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->pos, 3 * sizeof(double), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->vel, 3 * sizeof(double), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->acc, 3 * sizeof(double), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->mass, sizeof(double), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->radius, sizeof(double), s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->dyn, 1, s->n));
+    NB_TRY(refresh_gather(s->stream, s->rb, s->order_d, sizeof(uint32_t), s->n));
+    s->order_stale = true;
+    if (s->alg == NB_ALG_DIRECT) {
+        s->ds.cur = 0;
+        NB_TRY(pack_posm3(s->stream, s->pos, s->mass, s->radius, s->n, s->units, s->p.collision_th, s->ds.posm[0], s->ds.wcut,
+                          s->ds.rad));
+        NB_HIP(hipMemcpyAsync(s->ds.posm[1], s->ds.posm[0], sizeof(float4) * 2 * direct3_record_capacity(s->n),
+                              hipMemcpyDeviceToDevice, s->stream));
+    }
+    s->steps_in_order = 0;
+    return NB_OK;
+}
+
 // The device state in the caller's order; half_kick > 0 adds a(x) * half_kick to the velocities.
 int read_state(nb_sim3 *s, nb_body3 *out, double half_kick)
 {
@@ -278,6 +333,7 @@ int read_state(nb_sim3 *s, nb_body3 *out, double half_kick)
     std::vector<uint8_t> dyn(n);
     const size_t tri = sizeof(double) * 3 * (size_t)n;
     NB_HIP(hipStreamSynchronize(s->stream));
+    NB_TRY(host_order(s));
     NB_HIP(hipMemcpy(pos.data(), s->pos, tri, hipMemcpyDeviceToHost));
     NB_HIP(hipMemcpy(vel.data(), s->vel, tri, hipMemcpyDeviceToHost));
     NB_HIP(hipMemcpy(acc.data(), s->acc, tri, hipMemcpyDeviceToHost));
@@ -349,7 +405,9 @@ int nb3_create(const nb_params *params, int n, int alg, nb_sim3 **out)
     chk(dev_alloc(s->mass, cap));
     chk(dev_alloc(s->radius, cap));
     chk(dev_alloc(s->dyn, cap));
+    chk(dev_alloc(s->order_d, cap));
     if (alg == NB_ALG_DIRECT) {
+        chk(refresh_alloc(s->rb, n));  // nb3_step renews the order by itself for the direct sum
         chk(dev_alloc(s->pos2, 3 * cap));
         chk(dev_alloc(s->ds.posm[0], 2 * direct3_record_capacity(n)));
         chk(dev_alloc(s->ds.posm[1], 2 * direct3_record_capacity(n)));
@@ -428,20 +486,37 @@ int nb3_step(nb_sim3 *s, int nsteps)
         return fail(NB_ERR_STATE, "nb3_step: no bodies were set");
     if (s->world != 1)
         return fail(NB_ERR_STATE, "nb3_step: a partitioned simulation steps with nb3_step_local / nb3_step_finish");
-    // direct sum: bodies wander, so the spatial order its run-against-block tests rely on is
+    // direct sum: bodies wander, so the spatial order its run-against-wave box tests rely on is
     // renewed now and then (same rule as nb_step)
-    long interval = 50000000L / s->n;
-    interval = interval < 64 ? 64 : (interval > 4096 ? 4096 : interval);
+    const long interval = refresh_interval(s->n);
     for (int k = 0; k < nsteps; ++k) {
         NB_TRY(step_local(s, 1));
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
-        if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= interval) {
-            std::vector<nb_body3> b(s->n);
-            NB_TRY(read_state(s, b.data(), 0.0));
-            NB_TRY(load_bodies(s, b.data(), s->n));
-        }
+        if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= interval)
+            NB_TRY(device_refresh(s));
     }
+    return NB_OK;
+}
+
+int nb3_refresh_order(nb_sim3 *s)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb3_refresh_order: sim is NULL");
+    if (!s->have_bodies)
+        return fail(NB_ERR_STATE, "nb3_refresh_order: no bodies were set");
+    if (s->mid_step)
+        return fail(NB_ERR_STATE, "nb3_refresh_order: a split step is in flight");
+    return device_refresh(s);
+}
+
+int nb3_velocity_buffer(nb_sim3 *s, void **device_ptr, size_t *chunk_records, size_t *record_bytes)
+{
+    if (!s || !device_ptr || !chunk_records || !record_bytes)
+        return fail(NB_ERR_ARG, "nb3_velocity_buffer: NULL argument");
+    *device_ptr = s->vel;
+    *chunk_records = s->chunk;
+    *record_bytes = 3 * sizeof(double);
     return NB_OK;
 }
 
@@ -479,6 +554,11 @@ int nb3_step_distributed(nb_sim3 *s, int nsteps)
         mark(s, s->alg == NB_ALG_DIRECT ? 2 : 7);
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
+        if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= refresh_interval(s->n)) {
+            if (s->world > 1)
+                NB_TRY(comm_all_gather_f64(s->comm, s->vel, 3 * s->chunk, s->stream));
+            NB_TRY(device_refresh(s));
+        }
     }
     return NB_OK;
 }
@@ -674,8 +754,10 @@ int nb3_debug_read(nb_sim3 *s, int which, void *out, size_t bytes, size_t *writt
             *written = need;
         return NB_OK;
     };
-    if (which == NB_DBG_ORDER)
+    if (which == NB_DBG_ORDER) {
+        NB_TRY(host_order(s));
         return give(s->order.data(), sizeof(uint32_t) * s->n, false);
+    }
     if (s->alg != NB_ALG_BARNES_HUT)
         return fail(NB_ERR_STATE, "nb3_debug_read: not a Barnes-Hut simulation");
     constexpr int LS = BH_MAX_DEPTH + 2;

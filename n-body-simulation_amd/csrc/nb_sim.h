@@ -6,6 +6,7 @@
 #include "nb_bh.h"
 #include "nb_comm.h"
 #include "nb_common.h"
+#include "nb_refresh.h"
 #include "nb_timing.h"
 
 struct nb_sim {
@@ -35,6 +36,8 @@ struct nb_sim {
     int cur = 0;
     std::vector<uint32_t> order;  // caller index of the body in each exchange-order slot
     uint32_t *order_d = nullptr;  // the same on the device
+    bool order_stale = false;     // the device renewed the order; `order` is fetched when next needed
+    nb::RefreshBuffers rb;        // buffers of the renewal (made at nb_create for the direct sum, else on first use)
 
     // partition
     int rank = 0, world = 1;

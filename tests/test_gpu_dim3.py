@@ -415,3 +415,32 @@ def test_a_drifting_system_keeps_its_precision_in_the_tree_path(nb, oracle, dims
     at = out.copy()
     ref = accel(at)
     assert rel_err(acc, ref).max() <= BH_TOL, rel_err(acc, ref).max()
+
+
+@pytest.mark.parametrize("alg", ["direct", "bh"])
+def test_refresh_order_changes_nothing_the_caller_sees_3d(nb, oracle, alg):
+    """nb3_refresh_order re-sorts the device state by the current positions, on the device; the run
+    goes on as before up to the rounding of a different summation order."""
+    n = 3000
+    b0 = oracle.scenario3(0, n, 23, thickness=5.0e10)
+    algc = nb.DIRECT if alg == "direct" else nb.BARNES_HUT
+    with nb.NBodySim3(n, algc) as a:
+        a.set_bodies(b0)
+        a.update(40)
+        ra = a.read_bodies()
+    with nb.NBodySim3(n, algc) as c:
+        c.set_bodies(b0)
+        c.update(20)
+        before = c.order().copy()
+        mid = c.read_bodies()
+        c.refresh_order()
+        after = c.order()
+        assert np.array_equal(np.sort(after), np.arange(n)) and not np.array_equal(before, after)
+        again = c.read_bodies()
+        for f in ("pos", "vel", "acc", "mass", "radius", "is_dynamic"):
+            assert np.array_equal(mid[f], again[f])
+        c.update(20)
+        rc = c.read_bodies()
+    scale = np.abs(ra["pos"]).max()
+    assert np.abs(ra["pos"] - rc["pos"]).max() / scale < 1e-7
+    assert np.abs(ra["vel"] - rc["vel"]).max() / np.abs(ra["vel"]).max() < 1e-5
