@@ -314,10 +314,10 @@ def main():
     direct = None
     if not args.no_direct:
         direct = {}
-        # N = 65,536: a step takes 1 ms and the GPU needs some 20 ms of work to reach its steady
-        # clocks (measured: 4.1 T/s over the first 10 steps, 4.6-4.7 T/s from step 20 on), so
-        # this leg warms up for 30 steps and times 40
-        for n, steps, warm in ((65536, max(args.steps, 40), 30), (args.direct_n, 3, 1)):
+        # N = 65,536: a step takes 0.9 ms; after the idle stretch in which the bodies are made and
+        # uploaded the GPU needs some 20 ms of work to be back at its steady clocks, so this leg
+        # times 200 steps (5 warm-up steps): the ramp is inside the timed region and weighs 1/10
+        for n, steps, warm in ((65536, max(args.steps, 200), 5), (args.direct_n, 3, 1)):
             b = nb.init_scenario(nb.SPIRAL, n, 12345)
             ddt, dstages, _, _ = timed_run(nb, nb.DIRECT, b, steps, warm, rank, world, device)
             gi = float(n) * n * steps / ddt / 1e9
