@@ -176,6 +176,33 @@ int nb_comm_unique_id(void *id, size_t bytes);
 int nb_comm_init(nb_sim *sim, int rank, int world, const void *id);
 int nb_step_distributed(nb_sim *sim, int nsteps);
 
+/* What the ranks exchange each step (Barnes-Hut; no counterpart in the reference).
+ * NB_EXCHANGE_POSITIONS (default): every rank keeps all positions up to date (one all-gather) and
+ * rebuilds the whole tree itself -- sort, build and centres of mass cost every rank the full N.
+ * NB_EXCHANGE_CELLS: a rank sorts only the bodies it integrates and describes every cell of the
+ * level at which the tree closes (no body ever opens a cell of that level: with the reference's
+ * constants level 8-9, a few hundred thousand cells) by one record -- sum m x, sum m y, sum m, count,
+ * and, where it holds exactly one body there, that body's position and radius; the records are
+ * added up over the ranks (one all-reduce, 64 bytes a cell) and every rank builds the same tree from
+ * the totals.  Cells with one body in all keep that body's exact position and radius, so every
+ * accept/drop decision is the reference's; centres of mass of shared cells are summed in another
+ * order than on one GPU (differences of the order of 1e-16).  Per step: one max-reduction of 4
+ * doubles (the bounding box) and the sum-reduction of the records; no rank needs another rank's
+ * bodies, so nb_read_bodies all-gathers the positions first when the library holds the communicator
+ * (a collective call then) and returns only this rank's velocities up to date.  Needs a tree that
+ * closes at level <= 10, Euler integration and bucket_depth 0; switch it on after nb_set_partition /
+ * nb_comm_init and before the first step.  Every 16 steps the host waits for the stream once.
+ *
+ * With nb_comm_init, nb_step_distributed does all of this.  With another collective:
+ *   nb_step_cells(sim, 0); reduce nb_cells_buffer(sim, 0, ..) over the ranks with MAX, in place;
+ *   nb_step_cells(sim, 1); reduce nb_cells_buffer(sim, 1, ..) over the ranks with SUM, in place;
+ *   nb_step_cells(sim, 2);
+ * (buffers of doubles; ask for buffer 1 after part 1 of each step: its length follows the box). */
+enum nb_exchange { NB_EXCHANGE_POSITIONS = 0, NB_EXCHANGE_CELLS = 1 };
+int nb_set_exchange(nb_sim *sim, int mode);
+int nb_step_cells(nb_sim *sim, int part);
+int nb_cells_buffer(nb_sim *sim, int which, void **device_ptr, size_t *count_doubles);
+
 /* ---- introspection used by the tests and the benchmark ---- */
 
 enum nb_debug_array {

@@ -492,6 +492,8 @@ int nb_step_local(nb_sim *s)
         return fail(NB_ERR_STATE, "nb_step_local: no bodies were set");
     if (s->mid_step)
         return fail(NB_ERR_STATE, "nb_step_local: the previous step was not finished");
+    if (s->exchange == NB_EXCHANGE_CELLS)
+        return fail(NB_ERR_STATE, "nb_step_local: with the cell exchange a step goes through nb_step_cells");
     NB_TRY(step_local(s, 1));
     s->mid_step = true;
     return NB_OK;
@@ -531,6 +533,139 @@ int nb_step(nb_sim *s, int nsteps)
     return NB_OK;
 }
 
+// ---- cell exchange ----
+
+// The rank's own bodies as a simulation of their own: arrays offset to slot t0, n = their number.
+static BhStepArgs cells_args(nb_sim *s, int do_integrate)
+{
+    BhStepArgs a = bh_args(s, do_integrate);
+    const size_t off = (size_t)s->t0;
+    a.pos += off;
+    a.mass += off;
+    a.radius += off;
+    a.mass_radius += off;
+    a.dyn += off;
+    a.vel += off;
+    a.acc += off;
+    a.pos_out += off;
+    a.n = s->t1 - s->t0;
+    a.t0 = 0;
+    a.t1 = a.n;
+    return a;
+}
+
+// Digits for the keys of the coming steps, from the box of the last finished step (the caller has
+// waited for the stream, so every rank reads the same box): the level at which a box half as large
+// again would close the tree, so that the box may grow for a while.  -1: deeper than the dense
+// pyramid goes.
+static int choose_cells_levels(nb_sim *s)
+{
+    const double w = ((volatile double *)s->bh.hint_box)[0], h = ((volatile double *)s->bh.hint_box)[1];
+    const int l = closed_level_for(1.5 * w, 1.5 * h, s->p.theta, s->p.collision_th);
+    return l <= cells_max_level() ? l : -1;
+}
+
+int nb_set_exchange(nb_sim *s, int mode)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_set_exchange: sim is NULL");
+    if (mode != NB_EXCHANGE_POSITIONS && mode != NB_EXCHANGE_CELLS)
+        return fail(NB_ERR_ARG, "nb_set_exchange: unknown mode");
+    if (s->mid_step || s->cells_phase != 0)
+        return fail(NB_ERR_STATE, "nb_set_exchange: a split step is in flight");
+    if (mode == NB_EXCHANGE_POSITIONS) {
+        if (s->exchange == NB_EXCHANGE_CELLS && s->stepped)
+            return fail(NB_ERR_STATE, "nb_set_exchange: after steps with the cell exchange this rank no longer holds the "
+                                      "other ranks' positions; set the bodies again");
+        s->exchange = mode;
+        return NB_OK;
+    }
+    if (s->alg != NB_ALG_BARNES_HUT || s->p.bucket_depth != 0 || s->p.integrator != NB_INT_EULER)
+        return fail(NB_ERR_ARG, "nb_set_exchange: the cell exchange is for Barnes-Hut with the reference's CPU tree and "
+                                "its Euler integration");
+    if (!s->have_bodies || s->stepped)
+        return fail(NB_ERR_STATE, "nb_set_exchange: switch the cell exchange on after the bodies and the partition were "
+                                  "set and before the first step");
+    NB_TRY(bh_cells_alloc(s->bh));
+    NB_HIP(hipStreamSynchronize(s->stream));
+    const int levels = choose_cells_levels(s);
+    if (levels < 0)
+        return fail(NB_ERR_OVERFLOW, "nb_set_exchange: with these parameters the tree closes below level " +
+                                         std::to_string(cells_max_level()) + "; use the position exchange");
+    s->cells_levels = levels;
+    s->cells_steps = 0;
+    s->exchange = mode;
+    return NB_OK;
+}
+
+// Every 16 steps the host waits for the stream and looks at the box the device left: the level of
+// the exchanged cells follows it (the same decision on every rank: the box is the reduced one).
+static int cells_housekeeping(nb_sim *s)
+{
+    if (s->cells_steps == 0 || s->cells_steps % 16 != 0)
+        return NB_OK;
+    NB_HIP(hipStreamSynchronize(s->stream));
+    if (*(volatile uint32_t *)s->bh.err_host != 0u)
+        return fail(NB_ERR_OVERFLOW, "cell exchange: the bounding box grew by more than half within 16 steps; the last "
+                                     "steps' tree was cut above the level it closes at");
+    const int levels = choose_cells_levels(s);
+    if (levels < 0)
+        return fail(NB_ERR_OVERFLOW, "cell exchange: the tree now closes below level " + std::to_string(cells_max_level()));
+    s->cells_levels = levels;
+    return NB_OK;
+}
+
+int nb_cells_buffer(nb_sim *s, int which, void **device_ptr, size_t *count)
+{
+    if (!s || !device_ptr || !count)
+        return fail(NB_ERR_ARG, "nb_cells_buffer: NULL argument");
+    if (s->exchange != NB_EXCHANGE_CELLS)
+        return fail(NB_ERR_STATE, "nb_cells_buffer: the cell exchange is not switched on");
+    if (which == 0) {
+        *device_ptr = s->bh.red4;
+        *count = 4;
+    } else if (which == 1) {
+        *device_ptr = s->bh.agg;
+        *count = cells_agg_doubles(s->cells_levels);
+    } else
+        return fail(NB_ERR_ARG, "nb_cells_buffer: which must be 0 or 1");
+    return NB_OK;
+}
+
+int nb_step_cells(nb_sim *s, int phase)
+{
+    if (!s)
+        return fail(NB_ERR_ARG, "nb_step_cells: sim is NULL");
+    if (s->exchange != NB_EXCHANGE_CELLS)
+        return fail(NB_ERR_STATE, "nb_step_cells: the cell exchange is not switched on");
+    if (phase != s->cells_phase)
+        return fail(NB_ERR_STATE, "nb_step_cells: the parts of a step go 0, 1, 2");
+    const BhStepArgs a = cells_args(s, 1);
+    if (phase == 0) {
+        NB_TRY(cells_housekeeping(s));
+        mark(s, 0);
+        NB_TRY(bh_cells_begin(s->stream, s->bh, a));
+    } else if (phase == 1) {
+        mark(s, 1);
+        NB_TRY(bh_cells_middle(s->stream, s->bh, a, s->cells_levels, 0));
+        mark(s, 2);
+        NB_TRY(bh_cells_middle(s->stream, s->bh, a, s->cells_levels, 1));
+        mark(s, 3);
+        mark(s, 4);
+        NB_TRY(bh_cells_middle(s->stream, s->bh, a, s->cells_levels, 2));
+    } else {
+        mark(s, 5);
+        NB_TRY(bh_cells_end(s->stream, s->bh, a, s->cells_levels));
+        mark(s, 6);
+        s->first_kick = false;
+        s->stepped = true;
+        s->cells_steps += 1;
+        NB_TRY(collect_timing(s));
+    }
+    s->cells_phase = (phase + 1) % 3;
+    return NB_OK;
+}
+
 int nb_comm_unique_id(void *id, size_t bytes)
 {
     if (bytes < COMM_ID_BYTES)
@@ -564,6 +699,22 @@ int nb_step_distributed(nb_sim *s, int nsteps)
         return fail(NB_ERR_STATE, "nb_step_distributed: no bodies were set");
     if (s->mid_step)
         return fail(NB_ERR_STATE, "nb_step_distributed: a split step is in flight");
+    if (s->exchange == NB_EXCHANGE_CELLS) {
+        // two reductions per step instead of the gather of all positions: the ranks' extents (4
+        // doubles, maximum) and the records of the cells of the keys' last level (sum)
+        if (s->cells_phase != 0)
+            return fail(NB_ERR_STATE, "nb_step_distributed: a split step is in flight");
+        for (int k = 0; k < nsteps; ++k) {
+            NB_TRY(nb_step_cells(s, 0));
+            if (s->world > 1)
+                NB_TRY(comm_all_reduce_max_f64(s->comm, s->bh.red4, 4, s->stream));
+            NB_TRY(nb_step_cells(s, 1));
+            if (s->world > 1)
+                NB_TRY(comm_all_reduce_sum_f64(s->comm, s->bh.agg, cells_agg_doubles(s->cells_levels), s->stream));
+            NB_TRY(nb_step_cells(s, 2));
+        }
+        return NB_OK;
+    }
     for (int k = 0; k < nsteps; ++k) {
         NB_TRY(step_local(s, 1));
         // the new positions of every rank's slice, in place, ordered on the stream with the kernels
@@ -593,6 +744,9 @@ int nb_compute_accel(nb_sim *s)
         return fail(NB_ERR_STATE, "nb_compute_accel: no bodies were set");
     if (s->mid_step)
         return fail(NB_ERR_STATE, "nb_compute_accel: a split step is in flight");
+    if (s->exchange == NB_EXCHANGE_CELLS)
+        return fail(NB_ERR_STATE, "nb_compute_accel: with the cell exchange this rank does not hold the other ranks' "
+                                  "positions");
     NB_TRY(step_local(s, 0));
     return collect_timing(s);
 }
@@ -617,7 +771,12 @@ int nb_read_bodies(nb_sim *s, nb_body *out)
     std::vector<uint8_t> dyn(n);
     // leapfrog keeps velocities half a step behind the positions; bring them level with the
     // force at the current positions
-    const bool half_step = s->p.integrator == NB_INT_LEAPFROG && !s->first_kick && !s->mid_step;
+    if (s->exchange == NB_EXCHANGE_CELLS && s->cells_phase != 0)
+        return fail(NB_ERR_STATE, "nb_read_bodies: a split step is in flight");
+    if (s->exchange == NB_EXCHANGE_CELLS && s->comm && s->world > 1)  // the other ranks' positions (a collective call)
+        NB_TRY(comm_all_gather_f64(s->comm, (double *)s->pos, 2 * s->chunk, s->stream));
+    const bool half_step = s->p.integrator == NB_INT_LEAPFROG && !s->first_kick && !s->mid_step &&
+                           s->exchange != NB_EXCHANGE_CELLS;
     if (half_step) {
         // this force evaluation is not a step: keep it out of the per-stage timing
         const int timing = s->timer.on;

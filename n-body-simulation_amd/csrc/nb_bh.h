@@ -27,7 +27,8 @@ struct BhBuffers {
     int sorted = 0;               // which of the two holds the sorted result (always 0: see bh_sort)
     uint32_t *cut = nullptr;      // [0] first tree level whose cells are never opened (32: none),
                                   // [1] levels the keys are computed to, [2] first sort pass with work,
-                                  // [3] 1: this step builds the dense pyramid, 0: the level-by-level tree
+                                  // [3] 1: this step builds the dense pyramid, 0: the level-by-level tree,
+                                  // [4] the level of the tree's leaves (= [1] except in a cell-exchange step)
     uint32_t *hist = nullptr;     // 256 x sort blocks
     uint32_t *hist_totals = nullptr;  // 256: keys per digit of the current pass
     int sort_blocks = 0;
@@ -50,10 +51,16 @@ struct BhBuffers {
     uint32_t *tblock = nullptr;   // per-block target counts (scratch of the compaction)
     unsigned long long *counters = nullptr;  // 8 statistics words
     uint32_t *levels_host = nullptr;  // pinned host word: tree levels of the last finished step
-    uint32_t *hint_host = nullptr;    // pinned host word: levels the keys of the last finished step held
+    uint32_t *hint_host = nullptr;    // pinned host word: level of the leaves of the last finished step's tree
+    double *hint_box = nullptr;       // pinned host: width and height of the last finished step's bounding box
+    uint32_t *err_host = nullptr;     // pinned host word: set when a cell-exchange step met a tree that closes
+                                      // deeper than the level the cells were exchanged at
     int launched = 0;                 // levels the per-level build kernels were launched for
     uint2 *pc_range = nullptr;        // dense pyramid: first and one-past-last sorted body of every cell of the
                                       // keys' last level (both zero: empty cell); null: no pyramid
+    double *agg = nullptr;            // cell exchange: one record per cell of the keys' last level (bh_cells_alloc)
+    double *red4 = nullptr;           // cell exchange: {-min x, max x, -min y, max y} of the own bodies
+    uint32_t *err = nullptr;          // (unused device word kept beside them)
     bool use_pyr = false;             // this step's kernels are launched for the dense-pyramid build ...
     int pyr_levels = -1;              // ... and can do keys of up to this many levels (-1: not launched)
 };
@@ -121,5 +128,14 @@ int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
 int bh_build(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
 int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
 int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
+
+// Cell exchange between GPUs (see nb_bh.hip): a step in three parts around two reductions.
+int bh_cells_alloc(BhBuffers &b);
+int cells_max_level();
+size_t cells_agg_doubles(int cells_levels);
+int closed_level_for(double w0, double h0, double theta, double cth);
+int bh_cells_begin(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
+int bh_cells_middle(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_levels, int part);
+int bh_cells_end(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_levels);
 
 }  // namespace nb

@@ -19,6 +19,7 @@
 //              every lane applies its OWN opening test (barnesHut.cpp:70-71), so each body
 //              accepts exactly the cells the reference accepts for it.  Integration
 //              (barnesHut.cpp:108-123) is fused into the epilogue.
+#include <cmath>
 #include <type_traits>
 
 #include "nb_bh.h"
@@ -81,15 +82,19 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const double2 *pos, int n,
     }
 }
 
+// cells_levels >= 0 (cell exchange between GPUs): `part` is ONE record {-min x, max x, -min y, max y}
+// of all ranks' bodies (minima negated so that one max-reduction serves), and the keys get
+// cells_levels digits whatever level closes the tree (cut[4]); a tree that closes deeper than that
+// cannot be exchanged at this level: *err is set.
 __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk, double margin, int bucket_depth,
                                                     double theta, double cth, double *box, uint32_t *cut, int pyr_levels,
-                                                    uint32_t *hint_host)
+                                                    uint32_t *hint_host, double *hint_box, int cells_levels, uint32_t *err)
 {
     double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
     for (int i = threadIdx.x; i < nblk; i += 256) {
-        mnx = fmin(mnx, part[4 * i + 0]);
+        mnx = fmin(mnx, cells_levels >= 0 ? -part[4 * i + 0] : part[4 * i + 0]);
         mxx = fmax(mxx, part[4 * i + 1]);
-        mny = fmin(mny, part[4 * i + 2]);
+        mny = fmin(mny, cells_levels >= 0 ? -part[4 * i + 2] : part[4 * i + 2]);
         mxy = fmax(mxy, part[4 * i + 3]);
     }
 #pragma unroll
@@ -154,8 +159,46 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         // The dense-pyramid build runs when the host launched its kernels (pyr_levels >= 0) and
         // the keys stop at a level it covers; otherwise the level-by-level build does the step.
         cut[3] = (pyr_levels >= 0 && (int)cut[1] <= pyr_levels) ? 1u : 0u;
+        cut[4] = cut[1];  // the level of the tree's leaves
+        if (cells_levels >= 0) {
+            cut[1] = (uint32_t)cells_levels;
+            cut[2] = (uint32_t)sort_first_pass(2 * cells_levels);
+            cut[3] = 1u;
+            cut[4] = first_closed <= (uint32_t)cells_levels ? first_closed : (uint32_t)cells_levels;
+            if (first_closed > (uint32_t)cells_levels && err)
+                *err = 1u;
+        }
         if (hint_host)
-            *hint_host = cut[1];  // host-visible: sizes the next steps' launches (a stale value only costs speed)
+            *hint_host = cut[4];  // host-visible: sizes the next steps' launches (a stale value only costs speed)
+        if (hint_box) {           // host-visible: width and height of the box
+            hint_box[0] = box[2] - box[0];
+            hint_box[1] = box[1] - box[3];
+        }
+    }
+}
+
+// Cell exchange: this rank's extent as ONE record {-min x, max x, -min y, max y} (one block).
+__global__ __launch_bounds__(256) void k_bbox_pack(const double *part, int nblk, double *red4)
+{
+    double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        mnx = fmin(mnx, part[4 * i + 0]);
+        mxx = fmax(mxx, part[4 * i + 1]);
+        mny = fmin(mny, part[4 * i + 2]);
+        mxy = fmax(mxy, part[4 * i + 3]);
+    }
+    __shared__ double sh[256][4];
+    sh[threadIdx.x][0] = mnx;
+    sh[threadIdx.x][1] = mxx;
+    sh[threadIdx.x][2] = mny;
+    sh[threadIdx.x][3] = mxy;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int d = threadIdx.x;
+        double v = sh[0][d];
+        for (int t = 1; t < 256; ++t)
+            v = (d & 1) ? fmax(v, sh[t][d]) : fmin(v, sh[t][d]);
+        red4[d] = (d & 1) ? v : -v;
     }
 }
 
@@ -171,7 +214,7 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     b.use_pyr = hint <= (uint32_t)PYR_MAX_LEVEL;
     b.pyr_levels = b.use_pyr ? PYR_MAX_LEVEL : -1;  // the deepest key level the pyramid kernels can do
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, a.bucket_depth,
-                       a.theta, a.collision_th, b.box, b.cut, b.pyr_levels, b.hint_host);
+                       a.theta, a.collision_th, b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, -1, (uint32_t *)nullptr);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -1519,16 +1562,140 @@ constexpr int PYR_TOP_CELLS = 1365;  // levels 0..5 ...
 constexpr int PYR_TOP_STAGE = 512;   // ... and, when r = 6, the level-6 cells in batches of this many
 static_assert(pyr_split(PYR_MAX_LEVEL) <= 6, "k_pyr_top stages at most one level beyond the six it holds");
 
-// Levels r .. L: one block per cell of level r.
-__global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, const uint2 *pc_range)
+// The sums of pyr_short_sums / pyr_long_sums for the cell of every thread of a 256-thread block
+// (all threads call; range = {first, end} of the thread's cell, {0, 0} for none).  Long runs are
+// dealt to the block's four waves: they cluster in a few neighbouring cells, i.e. in one wave's
+// threads.
+__device__ __forceinline__ void block_leaf_sums(const double *leaf_sum, uint2 range, double (&sums)[4])
+{
+    __shared__ uint4 long_range[256];  // cells whose bodies span many chunks: first, end, owning thread
+    __shared__ double long_sum[256][4];
+    __shared__ int nlong;
+    sums[0] = sums[1] = sums[2] = sums[3] = 0.0;
+    if (threadIdx.x == 0)
+        nlong = 0;
+    __syncthreads();
+    if (pyr_short_sums(leaf_sum, range.x, range.y, sums)) {
+        const int at = atomicAdd(&nlong, 1);
+        long_range[at] = make_uint4(range.x, range.y, threadIdx.x, 0u);
+    }
+    __syncthreads();
+    for (int i = (int)(threadIdx.x >> 6); i < nlong; i += 4) {
+        const uint4 lr = long_range[i];
+        double extra[4];
+        pyr_long_sums(leaf_sum, lr.x, lr.y, extra);
+        if ((threadIdx.x & 63u) == 0u) {
+            long_sum[lr.z][0] = extra[0];
+            long_sum[lr.z][1] = extra[1];
+            long_sum[lr.z][2] = extra[2];
+            long_sum[lr.z][3] = extra[3];
+        }
+    }
+    __syncthreads();
+    const uint32_t c0 = range.x >> 6, cl = range.y > range.x + 1u ? (range.y - 1u) >> 6 : c0;
+    if (cl - c0 > LEAF_SEQ) {
+        sums[0] += long_sum[threadIdx.x][0];
+        sums[1] += long_sum[threadIdx.x][1];
+        sums[2] += long_sum[threadIdx.x][2];
+        sums[3] = fmax(sums[3], long_sum[threadIdx.x][3]);
+    }
+    __syncthreads();  // the shared arrays may be used again
+}
+
+// ---- cell exchange between GPUs ----
+// Every rank sorts only the bodies it integrates and describes each cell of the keys' last level by
+// one record of AGG_DOUBLES doubles: {sum m x, sum m y, sum m, x, y, radius, count, -} -- x, y and
+// radius are those of the rank's body when it has exactly one in the cell, else 0.  The records of
+// all ranks are added up (one all-reduce); where the total count is 1, the sums x, y, radius are
+// that one body's values to the bit (the others add zeros), so single bodies keep their exact
+// positions and radii, and every rank builds the same pyramid from the totals without ever seeing
+// another rank's bodies.
+constexpr int AGG_DOUBLES = 8;
+
+__global__ __launch_bounds__(256) void k_agg_fill(ComArgs a, const uint2 *pc_range, double *agg)
+{
+    const uint32_t ncell = 1u << (2 * (int)a.cut[1]);
+    for (uint32_t base = blockIdx.x * 256u; base < ncell; base += gridDim.x * 256u) {  // whole blocks go round
+        const uint32_t c = base + threadIdx.x;
+        const uint2 range = c < ncell ? pc_range[c] : make_uint2(0u, 0u);
+        const uint32_t count = range.y > range.x ? range.y - range.x : 0u;
+        double sums[4];
+        block_leaf_sums(a.leaf_sum, range, sums);
+        double rec[AGG_DOUBLES] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (count == 1u) {
+            const uint32_t o = a.idx[range.x];
+            const double2 p = a.pos[o];
+            const double2 mr = a.mass_radius[o];
+            rec[0] = p.x * mr.x;
+            rec[1] = p.y * mr.x;
+            rec[2] = mr.x;
+            rec[3] = p.x;
+            rec[4] = p.y;
+            rec[5] = mr.y;
+        } else if (count > 1u) {
+            rec[0] = sums[0];
+            rec[1] = sums[1];
+            rec[2] = sums[2];
+        }
+        rec[6] = (double)count;
+        if (c < ncell) {
+            double2 *o = (double2 *)agg + (size_t)(AGG_DOUBLES / 2) * c;
+#pragma unroll
+            for (int k = 0; k < AGG_DOUBLES / 2; ++k)
+                o[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+        }
+    }
+}
+
+// The leaf of cell c of the tree's last level L from the exchanged records of its 4^down cells of
+// the keys' last level (down = 0 or more: the keys may go deeper than the tree).
+__device__ __forceinline__ PyrCell pyr_leaf_from_cells(const ComArgs &a, const double *agg, uint32_t c, int level, int down,
+                                                       double width0)
+{
+    double t[AGG_DOUBLES - 1] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const uint32_t per = 1u << (2 * down);
+    for (uint32_t j = 0; j < per; ++j) {
+        const double2 *r = (const double2 *)agg + (size_t)(AGG_DOUBLES / 2) * ((size_t)c * per + j);
+        const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        t[0] += r0.x;
+        t[1] += r0.y;
+        t[2] += r1.x;
+        t[3] += r1.y;
+        t[4] += r2.x;
+        t[5] += r2.y;
+        t[6] += r3.x;
+    }
+    PyrCell leaf;
+    leaf.first = 0u;  // (sorted positions mean nothing across ranks)
+    leaf.count = (uint32_t)t[6];
+    leaf.child = 0u;
+    leaf.prune = __float_as_uint(-1.f);
+    if (leaf.count == 1u) {
+        const double ox = 0.5 * (a.box[0] + a.box[2]), oy = 0.5 * (a.box[1] + a.box[3]);
+        leaf.cx = t[3];
+        leaf.cy = t[4];
+        leaf.m = t[2];
+        leaf.rec = make_float4((float)((t[3] - ox) * a.inv_len), (float)((t[4] - oy) * a.inv_len), (float)(t[2] * a.inv_mass),
+                               -(float)((t[5] + a.cth) * a.inv_len));
+        leaf.w = -t[5];
+    } else if (leaf.count > 1u) {
+        leaf.m = t[2];
+        float prune = -1.f;
+        multi_body_record(a, t[0], t[1], t[2], 0.0, width0, leaf.cx, leaf.cy, leaf.rec, leaf.w, prune);
+        leaf.prune = __float_as_uint(prune);
+    }
+    return leaf;
+}
+
+// Levels r .. L: one block per cell of level r.  CELLS: the leaves come from the exchanged cell
+// records (agg) instead of this GPU's own sorted bodies (pc_range, leaf sums).
+template <bool CELLS>
+__global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, const uint2 *pc_range, const double *agg)
 {
     if (a.cut[3] == 0u)
         return;
     __shared__ PyrCell cells[PYR_SUB_CELLS];  // levels r..L of the block's cell
-    __shared__ uint4 long_range[256];   // cells whose bodies span many chunks: first, end, owning thread
-    __shared__ double long_sum[256][4];
-    __shared__ int nlong;
-    const int L = (int)a.cut[1];
+    const int L = (int)a.cut[4];
     const int r = pyr_split(L);
     const int sub = L - r;
     const uint32_t nroots = 1u << (2 * r), nleaf = 1u << (2 * sub);
@@ -1538,39 +1705,16 @@ __global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, co
             const uint32_t t = t0 + threadIdx.x;
             const bool mine = t < nleaf;
             const uint32_t c = root * nleaf + t;
-            const uint2 range = mine ? pc_range[c] : make_uint2(0u, 0u);
-            double sums[4] = {0.0, 0.0, 0.0, 0.0};
-            // long runs are dealt to the block's four waves (they cluster in a few neighbouring
-            // cells, i.e. in one wave's threads)
-            if (threadIdx.x == 0)
-                nlong = 0;
-            __syncthreads();
-            if (pyr_short_sums(a.leaf_sum, range.x, range.y, sums)) {
-                const int at = atomicAdd(&nlong, 1);
-                long_range[at] = make_uint4(range.x, range.y, threadIdx.x, 0u);
+            PyrCell leaf;
+            if (CELLS) {
+                leaf = pyr_leaf_from_cells(a, agg, mine ? c : 0u, L, (int)a.cut[1] - L, width0);
+            } else {
+                const uint2 range = mine ? pc_range[c] : make_uint2(0u, 0u);
+                double sums[4];
+                block_leaf_sums(a.leaf_sum, range, sums);
+                leaf = pyr_leaf(a, range.x, range.y, L, width0, sums);
             }
-            __syncthreads();
-            for (int i = (int)(threadIdx.x >> 6); i < nlong; i += 4) {
-                const uint4 lr = long_range[i];
-                double extra[4];
-                pyr_long_sums(a.leaf_sum, lr.x, lr.y, extra);
-                if ((threadIdx.x & 63u) == 0u) {
-                    long_sum[lr.z][0] = extra[0];
-                    long_sum[lr.z][1] = extra[1];
-                    long_sum[lr.z][2] = extra[2];
-                    long_sum[lr.z][3] = extra[3];
-                }
-            }
-            __syncthreads();
             if (mine) {
-                const uint32_t c0 = range.x >> 6, cl = range.y > range.x + 1u ? (range.y - 1u) >> 6 : c0;
-                if (cl - c0 > LEAF_SEQ) {
-                    sums[0] += long_sum[threadIdx.x][0];
-                    sums[1] += long_sum[threadIdx.x][1];
-                    sums[2] += long_sum[threadIdx.x][2];
-                    sums[3] = fmax(sums[3], long_sum[threadIdx.x][3]);
-                }
-                const PyrCell leaf = pyr_leaf(a, range.x, range.y, L, width0, sums);
                 cells[pyr_offset(sub) + t] = leaf;
                 pyr_store(a, node_meta, pyr_offset(L) + c, leaf);
             }
@@ -1636,7 +1780,7 @@ __global__ __launch_bounds__(256) void k_pyr_top(ComArgs a, uint4 *node_meta, ui
         }
         return;
     }
-    const int L = (int)a.cut[1];
+    const int L = (int)a.cut[4];
     const int r = pyr_split(L);
     const double width0 = a.box[2] - a.box[0];
     int held = r;  // the level held in LDS from which the sweep goes on
@@ -1678,26 +1822,11 @@ __global__ __launch_bounds__(256) void k_pyr_top(ComArgs a, uint4 *node_meta, ui
                                                  : (threadIdx.x == 3 ? (unsigned long long)(L + 1) : 0ull);
 }
 
+static ComArgs com_args(const BhBuffers &b, const BhStepArgs &a);
+
 int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
-    ComArgs c;
-    c.node_meta = b.node_meta;
-    c.level_start = b.level_start;
-    c.idx = b.idx[b.sorted];
-    c.pos = a.pos;
-    c.mass_radius = a.mass_radius;
-    c.posm_s = b.posm_s;
-    c.box = b.box;
-    c.node_com = b.node_com;
-    c.node_rec = b.node_rec;
-    c.node_aux = b.node_child;
-    c.inv_len = 1.0 / a.units.len_unit;
-    c.inv_mass = 1.0 / a.units.mass_unit;
-    c.theta = a.theta;
-    c.cut = b.cut;
-    c.leaf_sum = b.leaf_sum;
-    c.cth = a.collision_th;
-    c.bucket = a.bucket_depth > 0 ? 1 : 0;
+    const ComArgs c = com_args(b, a);
     hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[b.sorted], b.idx[b.sorted], a.n, a.pos,
                        a.mass_radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum, b.chunk_info, b.cut, b.pc_range);
     if (b.use_pyr) {
@@ -1707,7 +1836,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
         // step's keys are deeper)
         const uint32_t hint = *(volatile const uint32_t *)b.hint_host;
         const dim3 grid(1u << (2 * pyr_split((int)(hint <= (uint32_t)PYR_MAX_LEVEL ? hint : (uint32_t)PYR_MAX_LEVEL))));
-        hipLaunchKernelGGL(k_pyr_sub, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range);
+        hipLaunchKernelGGL(k_pyr_sub<false>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range, (const double *)nullptr);
         hipLaunchKernelGGL(k_pyr_top, dim3(1), dim3(256), 0, s, c, b.node_meta, b.level_start, b.counters, b.keys[b.sorted],
                            (Split<2> *)b.split, b.bsum, a.n, b.levels_host, b.chunk_info);
         NB_HIP(hipGetLastError());
@@ -1727,6 +1856,29 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
         hipLaunchKernelGGL(k_com, dim3(1), dim3(256), 0, s, c, 0, top);
     NB_HIP(hipGetLastError());
     return NB_OK;
+}
+
+static ComArgs com_args(const BhBuffers &b, const BhStepArgs &a)
+{
+    ComArgs c;
+    c.node_meta = b.node_meta;
+    c.level_start = b.level_start;
+    c.idx = b.idx[b.sorted];
+    c.pos = a.pos;
+    c.mass_radius = a.mass_radius;
+    c.posm_s = b.posm_s;
+    c.box = b.box;
+    c.node_com = b.node_com;
+    c.node_rec = b.node_rec;
+    c.node_aux = b.node_child;
+    c.inv_len = 1.0 / a.units.len_unit;
+    c.inv_mass = 1.0 / a.units.mass_unit;
+    c.theta = a.theta;
+    c.cut = b.cut;
+    c.leaf_sum = b.leaf_sum;
+    c.cth = a.collision_th;
+    c.bucket = a.bucket_depth > 0 ? 1 : 0;
+    return c;
 }
 
 // ------------------------------------------------------------------ 6 traversal + integration
@@ -2276,6 +2428,104 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     return NB_OK;
 }
 
+// ------------------------------------------------------------------ cell exchange (multi-GPU)
+//
+// A step in three parts, with two reductions over the ranks in between (done by the caller: RCCL in
+// nb_step_distributed, anything else through nb_cells_buffer).  `a` describes THIS RANK'S bodies
+// only: n = their number, the per-body arrays offset to the first of them.
+//   begin:   own extent -> b.red4 {-min x, max x, -min y, max y}              [max over the ranks]
+//   middle:  box and levels from the reduced extent, keys / sort / leaf pass of the own bodies,
+//            one record per cell of the keys' last level -> b.agg             [sum over the ranks]
+//   end:     pyramid from the summed records, traversal + integration of the own bodies.
+// cells_levels: digits of the keys (host-chosen, the same on every rank; the tree must close at or
+// above that level, else *b.err_host is set and the results of the step are not the reference's).
+
+size_t cells_agg_doubles(int cells_levels) { return (size_t)AGG_DOUBLES << (2 * cells_levels); }
+
+int bh_cells_alloc(BhBuffers &b)
+{
+    if (b.agg)
+        return NB_OK;
+    if (!b.pc_range || !b.owned)
+        return fail(NB_ERR_STATE, "cell exchange needs a handle's own Barnes-Hut buffers");
+    NB_TRY(dev_alloc(b.agg, cells_agg_doubles(PYR_MAX_LEVEL)));
+    NB_TRY(dev_alloc(b.red4, 4));
+    NB_TRY(dev_alloc(b.err, 1));
+    return NB_OK;
+}
+
+int cells_max_level() { return PYR_MAX_LEVEL; }
+
+// Level at which a tree over a box of width w0 and height h0 closes (k_bbox_final's rule; 32: none).
+int closed_level_for(double w0, double h0, double theta, double cth)
+{
+    int first_closed = 32;
+    for (int l = BH_KEY_LEVELS; l >= 0; --l) {
+        const double w = std::ldexp(w0, -l), h = std::ldexp(h0, -l);
+        const double reach = cth * (1.0 - 1.0e-4) - std::sqrt(w * w + h * h);
+        if (reach > 0.0 && reach * (1.0 - 1.0e-4) > w / theta)
+            first_closed = l;
+        else
+            break;
+    }
+    return first_closed;
+}
+
+int bh_cells_begin(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
+{
+    int blocks = (a.n + 255) / 256;
+    if (blocks > BBOX_BLOCKS)
+        blocks = BBOX_BLOCKS;
+    if (blocks > 0)
+        hipLaunchKernelGGL(k_bbox_partial, dim3(blocks), dim3(256), 0, s, a.pos, a.n, b.bbox_part);
+    hipLaunchKernelGGL(k_bbox_pack, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, b.red4);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+// part 0: box and keys, 1: sort, 2: leaf pass and cell records (three calls, so that the caller can
+// time them apart).
+int bh_cells_middle(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_levels, int part)
+{
+    if (cells_levels < 0 || cells_levels > PYR_MAX_LEVEL)
+        return fail(NB_ERR_ARG, "bh_cells_middle: bad level");
+    if (part == 0) {
+        b.use_pyr = true;
+        b.pyr_levels = PYR_MAX_LEVEL;
+        b.sorted = 0;
+        hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.red4, 1, a.bbox_margin, 0, a.theta, a.collision_th,
+                           b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, cells_levels, b.err_host);
+        NB_HIP(hipGetLastError());
+        return a.n > 0 ? bh_keys(s, b, a) : (int)NB_OK;
+    }
+    if (part == 1)
+        return a.n > 0 ? sort_pairs(s, b.keys, b.idx, a.n, b.cut, b.hist, b.hist_totals) : (int)NB_OK;
+    const ComArgs c = com_args(b, a);
+    if (a.n > 0) {
+        hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[0], b.idx[0], a.n, a.pos,
+                           a.mass_radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum, b.chunk_info, b.cut, b.pc_range);
+    } else {
+        // no own bodies: every cell slot reads as empty
+        NB_HIP(hipMemsetAsync(b.pc_range, 0, sizeof(uint2) << (2 * cells_levels), s));
+    }
+    const uint32_t ncell = 1u << (2 * cells_levels);
+    const uint32_t blocks = (ncell + 255u) / 256u;
+    hipLaunchKernelGGL(k_agg_fill, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, s, c, b.pc_range, b.agg);
+    NB_HIP(hipGetLastError());
+    return NB_OK;
+}
+
+int bh_cells_end(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_levels)
+{
+    const ComArgs c = com_args(b, a);
+    const dim3 grid(1u << (2 * pyr_split(cells_levels)));
+    hipLaunchKernelGGL(k_pyr_sub<true>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range, b.agg);
+    hipLaunchKernelGGL(k_pyr_top, dim3(1), dim3(256), 0, s, c, b.node_meta, b.level_start, b.counters, b.keys[0],
+                       (Split<2> *)b.split, b.bsum, a.n, b.levels_host, b.chunk_info);
+    NB_HIP(hipGetLastError());
+    return bh_force(s, b, a);
+}
+
 // ------------------------------------------------------------------ buffers
 
 // Every device array of the pipeline for n bodies, taken from `alloc` (hipMalloc for a handle's
@@ -2289,7 +2539,7 @@ static int bh_layout(BhBuffers &b, int n, bool with_pyramid, Alloc &&alloc)
         b.node_cap = PYR_CELLS;  // the dense pyramid uses one node slot per cell
     b.sort_blocks = sort_blocks(n);
     NB_TRY(alloc(b.box, 4));
-    NB_TRY(alloc(b.cut, 4));
+    NB_TRY(alloc(b.cut, 8));
     NB_TRY(alloc(b.leaf_sum, 4 * (size_t)n));
     NB_TRY(alloc(b.chunk_info, (size_t)n / 64 + 2));
     NB_TRY(alloc(b.bbox_part, 4 * BBOX_BLOCKS));
@@ -2329,6 +2579,9 @@ int bh_alloc(BhBuffers &b, int n)
     *b.levels_host = 0u;
     b.hint_host = b.levels_host + 1;
     *b.hint_host = 0xffffffffu;  // key levels not known yet: bh_prime finds out
+    b.hint_box = (double *)(b.levels_host + 4);
+    b.err_host = b.levels_host + 8;
+    *b.err_host = 0u;
     return NB_OK;
 }
 
@@ -2387,6 +2640,9 @@ void bh_free(BhBuffers &b)
         (void)hipFree(b.tblock);
         (void)hipFree(b.counters);
         (void)hipFree(b.pc_range);
+        (void)hipFree(b.agg);
+        (void)hipFree(b.red4);
+        (void)hipFree(b.err);
         if (b.levels_host)
             (void)hipHostFree(b.levels_host);
     }

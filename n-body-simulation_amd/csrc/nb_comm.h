@@ -24,6 +24,8 @@ int comm_rank(const Comm *c);
 int comm_world(const Comm *c);
 // In-place all-gather of doubles on `stream`: rank k contributes buf[k * count, (k + 1) * count).
 int comm_all_gather_f64(Comm *c, double *buf, size_t count, hipStream_t stream);
+// In-place maximum over the ranks of `count` doubles.
+int comm_all_reduce_max_f64(Comm *c, double *buf, size_t count, hipStream_t stream);
 // In-place sum over the ranks of `count` doubles.
 int comm_all_reduce_sum_f64(Comm *c, double *buf, size_t count, hipStream_t stream);
 

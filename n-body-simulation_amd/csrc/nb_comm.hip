@@ -129,6 +129,13 @@ int comm_all_gather_f64(Comm *c, double *buf, size_t count, hipStream_t stream)
     return check(r, r->all_gather(buf + (size_t)c->rank * count, buf, count, ncclDouble, c->comm, stream), "ncclAllGather");
 }
 
+int comm_all_reduce_max_f64(Comm *c, double *buf, size_t count, hipStream_t stream)
+{
+    const Rccl *r = nullptr;
+    NB_TRY(rccl(r));
+    return check(r, r->all_reduce(buf, buf, count, ncclDouble, ncclMax, c->comm, stream), "ncclAllReduce");
+}
+
 int comm_all_reduce_sum_f64(Comm *c, double *buf, size_t count, hipStream_t stream)
 {
     const Rccl *r = nullptr;

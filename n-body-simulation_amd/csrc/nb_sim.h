@@ -45,6 +45,10 @@ struct nb_sim {
     int t0 = 0, t1 = 0;
     bool mid_step = false;
     nb::Comm *comm = nullptr;  // RCCL communicator of nb_comm_init (null: none)
+    int exchange = 0;          // nb_exchange: what the ranks exchange each step
+    int cells_levels = -1;     // cell exchange: digits of the keys (the same on every rank)
+    long cells_steps = 0;      // cell exchange: steps since it was switched on
+    int cells_phase = 0;       // cell exchange by hand: the next part of the step (0, 1, 2)
 
     // direct sum
     double2 *part = nullptr;

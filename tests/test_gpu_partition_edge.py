@@ -160,3 +160,96 @@ def test_partitioned_ranks_renew_their_order_together(nb, oracle, dims, alg):
         assert np.linalg.norm(o["pos"] - ref["pos"], axis=1).max() <= 1e-7 * extent
         own = orders[0][r * chunk:min(n, (r + 1) * chunk)]
         assert np.linalg.norm(o["vel"][own] - ref["vel"][own], axis=1).max() <= 0.1
+
+
+def reduce_between_ranks(hip, ranks, which, op):
+    """In-place reduction (op = np.maximum or np.add) of the cell-exchange buffer `which` of handles
+    that share one GPU, through the host."""
+    for s in ranks:
+        s.sync()
+    bufs = [s.cells_buffer(which) for s in ranks]
+    count = bufs[0][1]
+    assert all(b[1] == count for b in bufs)
+    total = None
+    for ptr, _ in bufs:
+        h = np.empty(count, dtype=np.float64)
+        assert hip.hipMemcpy(h.ctypes.data, ptr, 8 * count, 2) == 0
+        total = h if total is None else op(total, h)
+    for ptr, _ in bufs:
+        assert hip.hipMemcpy(ptr, total.ctypes.data, 8 * count, 1) == 0
+    assert hip.hipDeviceSynchronize() == 0
+
+
+@pytest.mark.parametrize("scenario,n,world", [(0, 3001, 2), (2, 20000, 3), (0, 5, 4), (0, 200000, 4)])
+def test_cell_exchange_reproduces_the_single_gpu_run(nb, oracle, scenario, n, world):
+    """NB_EXCHANGE_CELLS: every rank sorts only its own bodies; the ranks add up one record per cell
+    of the level at which the tree closes and build the same tree from the totals.  The accelerations
+    of every rank's bodies must be the reference's (bar 5e-6, as on one GPU) and the run must stay on
+    the single-GPU run's path."""
+    b = nb.init_scenario(nb.SOLAR if n == 5 else scenario, n, 17)
+    hip = _hip()
+    one = nb.NBodySim(n, nb.BARNES_HUT)
+    ranks = [nb.NBodySim(n, nb.BARNES_HUT) for _ in range(world)]
+    steps = 6
+    try:
+        one.set_bodies(b)
+        for r, s in enumerate(ranks):
+            s.set_bodies(b)
+            s.set_partition(r, world)
+            s.set_exchange(nb.EXCHANGE_CELLS)
+        order = ranks[0].order()
+        chunk = (n + world - 1) // world
+        for step in range(steps):
+            state = one.read_bodies()
+            one.update()
+            for s in ranks:
+                s.step_cells(0)
+            reduce_between_ranks(hip, ranks, 0, np.maximum)
+            for s in ranks:
+                s.step_cells(1)
+            reduce_between_ranks(hip, ranks, 1, np.add)
+            for s in ranks:
+                s.step_cells(2)
+            if step == 0:
+                # the accelerations the first step used, rank by rank, against the oracle's tree
+                ref = oracle.bh_accel(state)
+                for r, s in enumerate(ranks):
+                    own = order[min(n, r * chunk):min(n, (r + 1) * chunk)]
+                    acc = s.read_bodies()["acc"][own]
+                    dyn = state["is_dynamic"][own] != 0
+                    if dyn.any():
+                        err = np.linalg.norm(acc[dyn] - ref[own][dyn], axis=1) / np.linalg.norm(ref[own][dyn], axis=1)
+                        assert err.max() <= 5e-6, (r, err.max())
+        ref = one.read_bodies()
+        outs = [s.read_bodies() for s in ranks]
+    finally:
+        one.close()
+        for s in ranks:
+            s.close()
+    extent = np.abs(ref["pos"]).max()
+    for r, o in enumerate(outs):
+        own = order[min(n, r * chunk):min(n, (r + 1) * chunk)]
+        if len(own):  # (FP32 sums in another order over six steps: 2e-9 of the extent observed)
+            assert np.linalg.norm(o["pos"][own] - ref["pos"][own], axis=1).max() <= 1e-8 * extent
+            assert np.linalg.norm(o["vel"][own] - ref["vel"][own], axis=1).max() <= 0.1  # speeds are 1e4..1e5 m/s
+
+
+def test_cell_exchange_call_order(nb):
+    with nb.NBodySim(100, nb.BARNES_HUT) as sim:
+        sim.setup(nb.SPIRAL, 1)
+        with pytest.raises(nb.NBodyError, match="not switched on"):
+            sim.step_cells(0)
+        sim.set_partition(0, 2)
+        sim.set_exchange(nb.EXCHANGE_CELLS)
+        with pytest.raises(nb.NBodyError, match="0, 1, 2"):
+            sim.step_cells(1)
+        with pytest.raises(nb.NBodyError, match="nb_step_cells"):
+            sim.step_local()
+    with nb.NBodySim(100, nb.DIRECT) as sim:
+        sim.setup(nb.SPIRAL, 1)
+        with pytest.raises(nb.NBodyError, match="Barnes-Hut"):
+            sim.set_exchange(nb.EXCHANGE_CELLS)
+    with nb.NBodySim(100, nb.BARNES_HUT, nb.default_params(collision_th=1.0e7)) as sim:
+        sim.setup(nb.SPIRAL, 1)
+        with pytest.raises(nb.NBodyError, match="closes below level"):
+            sim.set_exchange(nb.EXCHANGE_CELLS)
