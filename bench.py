@@ -56,7 +56,8 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
-def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=True, params=None, late_at=0):
+def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=True, params=None, late_at=0,
+              cells=False):
     """Returns (seconds for `steps` steps, max over ranks; mean per-stage ms of this rank; traversal
     counters of rank 0; and, with late_at > 0, the same timing repeated once the run has reached
     step late_at: {"ms_per_step", "stage_ms", "at_step"})."""
@@ -66,14 +67,20 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
     sim.set_bodies(bodies)
     if world > 1 and REHEARSAL:
         # ranks sharing one GPU cannot form an RCCL group: the Python stepping layer over gloo
-        stepper = DistributedSim(GpuEngine(sim, device))
+        eng = GpuEngine(sim, device)
+        stepper = DistributedSim(eng)
+        if cells:
+            eng.use_cell_exchange()
         step = lambda: stepper.update(1)  # noqa: E731
     elif world > 1:
-        # the library's own communicator: one in-place ncclAllGather per step on the simulation's
-        # stream, no host synchronisation inside a step
+        # the library's own communicator: the step's collectives (one in-place ncclAllGather of the
+        # positions, or with the cell exchange two ncclAllReduce) are enqueued on the simulation's
+        # stream between its kernels, no host synchronisation inside a step
         cid = [nb.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(cid, src=0)
         sim.comm_init(rank, world, cid[0])
+        if cells:
+            sim.set_exchange(nb.EXCHANGE_CELLS)
         step = lambda: sim.step_distributed(1)  # noqa: E731
     else:
         step = lambda: sim.update(1)  # noqa: E731
@@ -251,6 +258,8 @@ def main():
     ap.add_argument("--no-direct", action="store_true", help="skip the direct-sum half of the metric")
     ap.add_argument("--no-50m", action="store_true", help="skip the Barnes-Hut N = 50M leg (BASELINE.json configs[4])")
     ap.add_argument("--big-n", type=int, default=50000000)
+    ap.add_argument("--position-exchange", action="store_true",
+                    help="N > 1: all-gather the positions every step instead of the cell exchange")
     ap.add_argument("--late-step", type=int, default=300, help="also time the headline run from this step on (0: no)")
     args = ap.parse_args()
 
@@ -292,9 +301,19 @@ def main():
 
     # ---- headline: Barnes-Hut, galaxy collision N = 5M ----
     bodies = nb.init_scenario(nb.COLLISION, args.bh_n, 12345)
+    # More than one GPU: the ranks exchange one record per cell of the level at which the tree
+    # closes (NB_EXCHANGE_CELLS) and each sorts only its own bodies; the mode BASELINE.json words
+    # (all-gather of the positions, whole tree rebuilt on every GPU) is timed beside it.
+    cells = world > 1 and not args.position_exchange
     dt, stages, counters, late = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device,
-                                           late_at=args.late_step)
+                                           late_at=args.late_step, cells=cells)
     ms_per_step = dt * 1e3 / args.steps
+    gathered = None
+    if cells:
+        pdt, pstages, _, _ = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device)
+        gathered = {"ms_per_step": pdt * 1e3 / args.steps, "stage_ms": pstages,
+                    "note": "the same workload with NB_EXCHANGE_POSITIONS: one all-gather of all positions per step, "
+                            "sort + tree + centres of mass repeated on every GPU"}
     # the same workload on the tree of the reference's GPU program (depth-9 cap, leaves as point
     # masses): the configuration the published 1509 ms was measured with
     gdt, gstages, gcounters, _ = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device,
@@ -305,7 +324,8 @@ def main():
     big = None
     if not args.no_50m:
         bodies = nb.init_scenario(nb.SPIRAL, args.big_n, 12345)
-        bdt, bstages, bcounters, _ = timed_run(nb, nb.BARNES_HUT, bodies, max(3, args.steps // 2), 2, rank, world, device)
+        bdt, bstages, bcounters, _ = timed_run(nb, nb.BARNES_HUT, bodies, max(3, args.steps // 2), 2, rank, world, device,
+                                               cells=cells)
         del bodies
         big = {"n": args.big_n, "scenario": "spiral", "ms_per_step": bdt * 1e3 / max(3, args.steps // 2),
                "stage_ms": bstages, "tree": bcounters}
@@ -383,13 +403,18 @@ def main():
             "workload": "galaxy collision N=%d Barnes-Hut theta=0.5, 2-D (BASELINE.json configs[3]); forces FP32, "
                         "state and integration FP64" % args.bh_n,
             "scenario_seed": 12345,
-            "parallelism": "targets split over %d GPU(s), tree rebuilt on every GPU, one in-place ncclAllGather of "
-                           "positions per step issued by the library on its own stream" % world,
+            "parallelism": ("one GPU" if world == 1 else
+                            "targets split over %d GPUs; %s, issued by the library on its own stream" % (
+                                world, "each rank sorts its own bodies, two ncclAllReduce per step (bounding box; one "
+                                       "record per cell of the level the tree closes at), same tree built on every GPU"
+                                if cells else "one in-place ncclAllGather of all positions per step, whole tree "
+                                              "rebuilt on every GPU")),
         },
         "speedup_vs_published": PUBLISHED_MS / ms_per_step,
         "stage_ms": stages,
         "tree": counters,
         "late_state": late,
+        "position_exchange": gathered,
         "barnes_hut_50m": big,
         "gpu_tree_mode": {"ms_per_step": gdt * 1e3 / args.steps, "bucket_depth": 9, "stage_ms": gstages, "tree": gcounters,
                           "speedup_vs_published": PUBLISHED_MS / (gdt * 1e3 / args.steps),

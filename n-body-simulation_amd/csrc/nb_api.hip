@@ -706,11 +706,9 @@ int nb_step_distributed(nb_sim *s, int nsteps)
             return fail(NB_ERR_STATE, "nb_step_distributed: a split step is in flight");
         for (int k = 0; k < nsteps; ++k) {
             NB_TRY(nb_step_cells(s, 0));
-            if (s->world > 1)
-                NB_TRY(comm_all_reduce_max_f64(s->comm, s->bh.red4, 4, s->stream));
+            NB_TRY(comm_all_reduce_max_f64(s->comm, s->bh.red4, 4, s->stream));
             NB_TRY(nb_step_cells(s, 1));
-            if (s->world > 1)
-                NB_TRY(comm_all_reduce_sum_f64(s->comm, s->bh.agg, cells_agg_doubles(s->cells_levels), s->stream));
+            NB_TRY(comm_all_reduce_sum_f64(s->comm, s->bh.agg, cells_agg_doubles(s->cells_levels), s->stream));
             NB_TRY(nb_step_cells(s, 2));
         }
         return NB_OK;
@@ -720,16 +718,14 @@ int nb_step_distributed(nb_sim *s, int nsteps)
         // the new positions of every rank's slice, in place, ordered on the stream with the kernels
         // before and after: the host does not wait
         double2 *buf = s->alg == NB_ALG_DIRECT ? s->pos2 : s->pos;
-        if (s->world > 1)
-            NB_TRY(comm_all_gather_f64(s->comm, (double *)buf, 2 * s->chunk, s->stream));
+        NB_TRY(comm_all_gather_f64(s->comm, (double *)buf, 2 * s->chunk, s->stream));
         mark(s, s->alg == NB_ALG_DIRECT ? 2 : 7);
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
         if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= refresh_interval(s->n)) {
             // every rank renews the order from the same positions; the new slices hold bodies other
             // ranks advanced so far, whose velocities come with one more all-gather
-            if (s->world > 1)
-                NB_TRY(comm_all_gather_f64(s->comm, (double *)s->vel, 2 * s->chunk, s->stream));
+            NB_TRY(comm_all_gather_f64(s->comm, (double *)s->vel, 2 * s->chunk, s->stream));
             NB_TRY(device_refresh(s));
         }
     }
@@ -773,7 +769,7 @@ int nb_read_bodies(nb_sim *s, nb_body *out)
     // force at the current positions
     if (s->exchange == NB_EXCHANGE_CELLS && s->cells_phase != 0)
         return fail(NB_ERR_STATE, "nb_read_bodies: a split step is in flight");
-    if (s->exchange == NB_EXCHANGE_CELLS && s->comm && s->world > 1)  // the other ranks' positions (a collective call)
+    if (s->exchange == NB_EXCHANGE_CELLS && s->comm)  // the other ranks' positions (a collective call)
         NB_TRY(comm_all_gather_f64(s->comm, (double *)s->pos, 2 * s->chunk, s->stream));
     const bool half_step = s->p.integrator == NB_INT_LEAPFROG && !s->first_kick && !s->mid_step &&
                            s->exchange != NB_EXCHANGE_CELLS;

@@ -549,14 +549,12 @@ int nb3_step_distributed(nb_sim3 *s, int nsteps)
     for (int k = 0; k < nsteps; ++k) {
         NB_TRY(step_local(s, 1));
         double *buf = s->alg == NB_ALG_DIRECT ? s->pos2 : s->pos;
-        if (s->world > 1)
-            NB_TRY(comm_all_gather_f64(s->comm, buf, 3 * s->chunk, s->stream));
+        NB_TRY(comm_all_gather_f64(s->comm, buf, 3 * s->chunk, s->stream));
         mark(s, s->alg == NB_ALG_DIRECT ? 2 : 7);
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
         if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= refresh_interval(s->n)) {
-            if (s->world > 1)
-                NB_TRY(comm_all_gather_f64(s->comm, s->vel, 3 * s->chunk, s->stream));
+            NB_TRY(comm_all_gather_f64(s->comm, s->vel, 3 * s->chunk, s->stream));
             NB_TRY(device_refresh(s));
         }
     }

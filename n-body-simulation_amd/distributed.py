@@ -55,6 +55,13 @@ class GpuEngine:
         self.sim.set_partition(rank, world)
         self.world = world
 
+    def use_cell_exchange(self):
+        """Switches the simulation to NB_EXCHANGE_CELLS (after set_partition, before the first step)."""
+        from . import EXCHANGE_CELLS
+
+        self.sim.set_exchange(EXCHANGE_CELLS)
+        self.cells = True
+
     def step_local(self):
         self.sim.step_local()
 
@@ -98,8 +105,29 @@ class DistributedSim:
                 if r != self.rank:
                     buf[r * self.chunk:(r + 1) * self.chunk].copy_(p)
 
+    def all_reduce_cells(self, which):
+        """In-place reduction over the ranks of the cell-exchange buffer `which` (0: extent, MAX; 1: cell
+        records, SUM) of an engine whose simulation runs the cell exchange."""
+        ptr, count = self.engine.sim.cells_buffer(which)
+        t = device_tensor(ptr, count, self.engine.device, 1).view(-1)
+        op = dist.ReduceOp.MAX if which == 0 else dist.ReduceOp.SUM
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(t, op=op, group=self.group)
+        else:
+            h = t.cpu()  # waits for the kernels queued on torch's current stream (the engine's)
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+
     def update(self, nsteps=1):
+        cells = getattr(self.engine, "cells", False)
         for _ in range(nsteps):
+            if cells:
+                self.engine.sim.step_cells(0)
+                self.all_reduce_cells(0)
+                self.engine.sim.step_cells(1)
+                self.all_reduce_cells(1)
+                self.engine.sim.step_cells(2)
+                continue
             self.engine.step_local()
             if self.world > 1:
                 self.all_gather_positions()

@@ -15,7 +15,9 @@
 // run), --thickness T (three-dimensional run: the scenario's bodies get heights in [-T, T]; frames
 // are then "NBDUMP3" records {x, y, z, vx, vy, vz, mass} and images are the x-y projection),
 // --gpus G (one process per GPU: the program starts G ranks of itself, each advances a slice of
-// the bodies and the positions are all-gathered with RCCL every step; rank 0 reports), --quiet.
+// the bodies; Barnes-Hut ranks exchange one record per cell of the level the tree closes at, or, with
+// --exchange positions or where that does not apply, all positions by an RCCL all-gather every step;
+// rank 0 reports), --quiet.
 #include <hip/hip_runtime_api.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -141,6 +143,7 @@ int main(int argc, char **argv)
     double thickness = -1;  // >= 0: three-dimensional run
     int integrator = NB_INT_EULER;
     int gpus = 1;
+    bool exchange_cells = true;
     std::vector<const char *> pos;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -177,6 +180,8 @@ int main(int argc, char **argv)
             thickness = std::atof(next("--thickness"));
         else if (a == "--gpus")
             gpus = std::atoi(next("--gpus"));
+        else if (a == "--exchange")
+            exchange_cells = std::string(next("--exchange")) != "positions";
         else if (a == "--quiet")
             quiet = true;
         else
@@ -327,8 +332,13 @@ int main(int argc, char **argv)
     }
     nbody::NBodySim nb(nBodies, alg, &params, seed);
     nb.setup(scenario);
-    if (gpus > 1)
+    if (gpus > 1) {
         nb.commInit(rank, gpus, comm_id);
+        // every rank takes the same decision: it depends on the parameters and the bodies only
+        if (alg == NB_ALG_BARNES_HUT && exchange_cells && integrator == NB_INT_EULER &&
+            nb_set_exchange(nb.handle(), NB_EXCHANGE_CELLS) != NB_OK && !quiet)
+            std::cout << "note: " << nb_last_error() << "; exchanging positions" << std::endl;
+    }
     auto print_energy = [&](const char *when) {
         double d[8];
         nb.diagnostics(d);

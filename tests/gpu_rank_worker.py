@@ -3,7 +3,7 @@ by pytest): every process holds its own simulation handle on cuda:0, the ranks e
 over gloo.  RCCL wants one GPU per rank, so this is as close as a one-GPU box gets to the
 multi-GPU launch: separate processes, the real engine, the real stepping protocol.
 
-    python gpu_rank_worker.py RANK WORLD PORT ALG DIMS N STEPS OUT_DIR
+    python gpu_rank_worker.py RANK WORLD PORT ALG DIMS N STEPS OUT_DIR [cells]
 """
 import os
 import sys
@@ -21,6 +21,7 @@ from oracle_lib import Oracle  # noqa: E402  (scenario generator of the checker:
 def main():
     rank, world, port, alg, dims, n, steps = (int(x) for x in sys.argv[1:8])
     out_dir = sys.argv[8]
+    cells = len(sys.argv) > 9 and sys.argv[9] == "cells"
     nb = load_package()
     from nbody_amd.distributed import DistributedSim, GpuEngine
 
@@ -35,7 +36,10 @@ def main():
         Sim = nb.NBodySim if dims == 2 else nb.NBodySim3
         with Sim(n, alg) as sim:
             sim.set_bodies(b)
-            stepper = DistributedSim(GpuEngine(sim, dev))
+            eng = GpuEngine(sim, dev)
+            stepper = DistributedSim(eng)
+            if cells:
+                eng.use_cell_exchange()
             stepper.update(steps)
             torch.cuda.synchronize()
             out = sim.read_bodies()

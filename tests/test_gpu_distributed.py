@@ -121,8 +121,32 @@ def test_native_rccl_world1_matches_plain_update(nb, oracle, alg, dims):
     assert ms["force"] > 0 and ms["exchange"] >= 0
 
 
-@pytest.mark.parametrize("alg,dims,world", [(0, 2, 2), (1, 2, 2), (1, 2, 3), (0, 3, 2), (1, 3, 2)])
-def test_separate_processes_step_one_system_together(nb, oracle, tmp_path, alg, dims, world):
+def test_native_rccl_world1_cell_exchange(nb, oracle):
+    """The cell exchange through the library's own communicator (ncclAllReduce with MAX and SUM on the
+    simulation's stream), world size 1: the same tree as the plain step (the keys carry one more
+    digit, so bodies of one closed cell are summed, and grouped for the traversal, in another order:
+    the runs agree to FP32 summation noise)."""
+    n = 30011
+    b = nb.init_scenario(nb.COLLISION, n, 4)
+    with nb.NBodySim(n, nb.BARNES_HUT) as plain, nb.NBodySim(n, nb.BARNES_HUT) as part:
+        plain.set_bodies(b)
+        part.set_bodies(b)
+        part.comm_init(0, 1, nb.comm_unique_id())
+        part.set_exchange(nb.EXCHANGE_CELLS)
+        part.set_stage_timing(True, counters=False)
+        plain.update(20)
+        part.step_distributed(20)  # crosses the 16-step look at the box
+        ms = part.stage_ms()
+        a = part.read_bodies()
+        ref = plain.read_bodies()
+    assert np.abs(a["pos"] - ref["pos"]).max() <= 1e-7 * np.abs(ref["pos"]).max()
+    assert np.abs(a["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
+    assert ms["force"] > 0
+
+
+@pytest.mark.parametrize("alg,dims,world,mode", [(0, 2, 2, ""), (1, 2, 2, ""), (1, 2, 3, ""), (0, 3, 2, ""), (1, 3, 2, ""),
+                                                 (1, 2, 2, "cells"), (1, 2, 3, "cells")])
+def test_separate_processes_step_one_system_together(nb, oracle, tmp_path, alg, dims, world, mode):
     """`world` processes, each with its own handle on the one GPU, advance one system through the
     stepping protocol (positions gathered over gloo).  Every rank must end with the positions of
     the unpartitioned run (up to FP32 summation order: the 64-body groups and the far/near run
@@ -134,7 +158,7 @@ def test_separate_processes_step_one_system_together(nb, oracle, tmp_path, alg, 
     port = _free_port()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_rank_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(alg), str(dims), str(n),
-                               str(steps), str(tmp_path)]) for r in range(world)]
+                               str(steps), str(tmp_path), mode]) for r in range(world)]
     codes = [p.wait(timeout=110) for p in procs]
     assert codes == [0] * world
     b = oracle.scenario(0, n, 5) if dims == 2 else oracle.scenario3(0, n, 5, thickness=6.0e10)
@@ -148,7 +172,9 @@ def test_separate_processes_step_one_system_together(nb, oracle, tmp_path, alg, 
         pos = np.load(tmp_path / ("pos_%d.npy" % r))
         vel = np.load(tmp_path / ("vel_%d.npy" % r))
         order = np.load(tmp_path / ("order_%d.npy" % r))
-        assert np.linalg.norm(pos - ref["pos"], axis=1).max() <= 1e-9 * 5e11
         own = order[r * chunk:(r + 1) * chunk]
+        # (with the cell exchange a rank holds only its own bodies' positions up to date)
+        sel = own if mode == "cells" else slice(None)
+        assert np.linalg.norm(pos[sel] - ref["pos"][sel], axis=1).max() <= 1e-9 * 5e11
         # orbital speeds are 1e4..1e5 m/s; FP32 summation-order noise adds up to ~1e-3 m/s over the steps
         assert np.linalg.norm(vel[own] - ref["vel"][own], axis=1).max() <= 1e-2
