@@ -283,8 +283,6 @@ int main(int argc, char **argv)
             return EXIT_FAILURE;
         }
         quiet = quiet || rank != 0;
-        if (rank != 0)
-            ppm.clear();
     }
 
     std::FILE *f = nullptr;
@@ -309,7 +307,7 @@ int main(int argc, char **argv)
                 nb3.readDeviceBodies();
                 if (f)
                     dump_frame3(f, nb3.getBodies(), nBodies, i + 1);
-                if (!ppm.empty()) {
+                if (!ppm.empty() && rank == 0) {
                     flat.assign(nBodies, nb_body{});
                     for (int k = 0; k < nBodies; ++k) {
                         flat[k].mass = nb3.getBodies()[k].mass;
@@ -354,7 +352,9 @@ int main(int argc, char **argv)
             nb.readDeviceBodies();
             if (f)
                 dump_frame(f, nb.getBodies(), nBodies, i + 1);
-            if (!ppm.empty()) {
+            // (every rank reads at the same steps: with the cell exchange the read gathers the
+            // positions over the ranks; rank 0 draws)
+            if (!ppm.empty() && rank == 0) {
                 char name[32];
                 std::snprintf(name, sizeof(name), "_%06d.ppm", i + 1);
                 write_ppm(ppm + name, nb.getBodies(), nBodies, window < 16 ? 16 : window);
