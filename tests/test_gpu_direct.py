@@ -140,6 +140,45 @@ def test_pairs_at_the_cutoff_follow_the_reference(nb, oracle):
     assert rel_err(acc, ref).max() <= ACC_TOL
 
 
+@pytest.mark.parametrize("dims", [2, 3])
+def test_pairs_at_a_tiny_cutoff_across_run_boundaries(nb, oracle, dims):
+    """A cutoff of 1e-5 of the system's extent (1e7 m), 2000 isolated pairs placed 7e2 .. 7e5 m
+    (1e-8 .. 1e-5 internal units: below and above the float rounding of the coordinates) either side
+    of it.  A pair lies next to itself in the exchange order, so some pairs straddle the boundary of
+    two runs of 256 sources, where the box of the one body's wave and the box of the other's run are
+    exactly the pair's distance apart: the shortcut that skips the cutoff test for far runs must
+    not take such a run, and the near runs' FP64 re-decision must reproduce the reference's skipped
+    set (directSum.cpp:69-72).  A pair on the wrong side changes its bodies' accelerations by orders
+    of magnitude (the pair is 100 times closer than any other body)."""
+    rng = np.random.default_rng(8)
+    n = 4001
+    cth = 1.0e7
+    if dims == 2:
+        b = oracle.scenario(1, n, 6)
+    else:
+        b = oracle.scenario3(1, n, 6, thickness=2.0e11)
+    th = 2 * 12756 + cth
+    for k in range(0, n - 2, 2):
+        u = rng.normal(size=dims)
+        u /= np.linalg.norm(u)
+        d = th + rng.choice([-1, 1]) * 10.0 ** rng.uniform(2.85, 5.85)
+        b["pos"][k + 1] = b["pos"][k] + d * u
+    po = oracle.params(collision_th=cth)
+    pn = nb.default_params(collision_th=cth)
+    if dims == 2:
+        acc = gpu_accel(nb, b, nb.DIRECT, pn)
+        ref = oracle.direct_accel(b, po)
+    else:
+        with nb.NBodySim3(n, nb.DIRECT, pn) as sim:
+            sim.set_bodies(b)
+            acc = sim.compute_accel()
+        ref = oracle.direct_accel3(b, po)
+    err = rel_err(acc, ref)
+    # the pairs just outside the cutoff dominate their bodies' sums and sit 1e-5 of the extent apart:
+    # their float distance carries ~1e-4 relative rounding unless the low parts are used, which they are
+    assert err.max() <= ACC_TOL, err.max()
+
+
 def test_softened_force_without_cutoff(nb, oracle):
     """collision_th = 0 with a large epsilon exercises the exact r^3 + eps^2 denominator."""
     n = 700
