@@ -34,6 +34,7 @@ PKG = os.path.join(ROOT, "n-body-simulation_amd")
 
 PUBLISHED_MS = 1509.0           # reference README.md:18, GPU Barnes-Hut N = 5M per iteration
 REHEARSAL = os.environ.get("NBODY_BENCH_REHEARSAL") == "1"
+TRANSPORT = {"used": None}      # who issued the collectives of the multi-GPU legs
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, spec
 VALU_PEAK_TFLOPS = 157.3        # MI355X FP32 vector peak, spec (256 CU x 128 lanes x 2 x 2.4 GHz)
 FLOP_PER_INTERACTION = 20       # GPU Gems 3 ch. 31 convention
@@ -76,12 +77,40 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
         # the library's own communicator: the step's collectives (one in-place ncclAllGather of the
         # positions, or with the cell exchange two ncclAllReduce) are enqueued on the simulation's
         # stream between its kernels, no host synchronisation inside a step
-        cid = [nb.comm_unique_id() if rank == 0 else None]
+        ok = 1
+        try:
+            cid = [nb.comm_unique_id() if rank == 0 else None]
+        except nb.NBodyError as e:  # librccl.so.1 not loadable: the same on every rank of this node
+            cid, ok = [None], 0
+            print("bench.py: rank %d: %s" % (rank, e), file=sys.stderr)
         dist.broadcast_object_list(cid, src=0)
-        sim.comm_init(rank, world, cid[0])
-        if cells:
-            sim.set_exchange(nb.EXCHANGE_CELLS)
-        step = lambda: sim.step_distributed(1)  # noqa: E731
+        if cid[0] is None:
+            ok = 0
+        if ok:
+            try:
+                sim.comm_init(rank, world, cid[0])
+                if cells:
+                    sim.set_exchange(nb.EXCHANGE_CELLS)
+            except nb.NBodyError as e:
+                ok = 0
+                print("bench.py: rank %d: %s" % (rank, e), file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()):
+            TRANSPORT["used"] = "library (librccl.so.1 loaded by libnbody_hip.so)"
+            step = lambda: sim.step_distributed(1)  # noqa: E731
+        else:
+            # some rank could not set the library's communicator up: the same protocol with the
+            # collectives issued by torch.distributed (which is RCCL as well), said so in the line
+            TRANSPORT["used"] = "torch.distributed (the library's own communicator failed, see stderr)"
+            sim.close()
+            sim = nb.NBodySim(len(bodies), alg, params)
+            sim.set_bodies(bodies)
+            eng = GpuEngine(sim, device)
+            stepper = DistributedSim(eng)
+            if cells:
+                eng.use_cell_exchange()
+            step = lambda: stepper.update(1)  # noqa: E731
     else:
         step = lambda: sim.update(1)  # noqa: E731
     for _ in range(warmup):
@@ -391,6 +420,7 @@ def main():
         "unit": "ms/step",
         "n_gpus": world,
         "rccl_ranks": rccl_ranks,
+        "collectives_by": TRANSPORT["used"] if not rehearsal else "torch.distributed over gloo (rehearsal)",
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,

@@ -160,11 +160,11 @@ long refresh_interval(int n)
 int step_local(nb_sim *s, int do_integrate)
 {
     if (s->alg == NB_ALG_DIRECT) {
-        mark(s, 0);
+        mark(s, 5);
         NB_TRY(direct_step(s->stream, s->posm[s->cur], s->posm[s->cur ^ 1], s->rad_s, s->n, s->t0, s->t1 - s->t0, s->fc,
                            integrate_args(s, do_integrate), s->dyn, s->pos, s->pos2, s->radius, s->p.collision_th,
                            s->vel, s->acc, s->part, s->jsplit, s->ds_meta));
-        mark(s, 1);
+        mark(s, 6);
         return NB_OK;
     }
     BhStepArgs a = bh_args(s, do_integrate);
@@ -202,7 +202,7 @@ int step_finish(nb_sim *s)
     return NB_OK;
 }
 
-int collect_timing(nb_sim *s) { return s->timer.step_done(s->stream, s->alg == NB_ALG_DIRECT); }
+int collect_timing(nb_sim *s) { return s->timer.step_done(s->stream); }
 
 void release(nb_sim *s)
 {
@@ -641,22 +641,26 @@ int nb_step_cells(nb_sim *s, int phase)
     if (phase != s->cells_phase)
         return fail(NB_ERR_STATE, "nb_step_cells: the parts of a step go 0, 1, 2");
     const BhStepArgs a = cells_args(s, 1);
+    constexpr int EXCHANGE = 6;  // the caller's collectives run between the parts
     if (phase == 0) {
         NB_TRY(cells_housekeeping(s));
         mark(s, 0);
         NB_TRY(bh_cells_begin(s->stream, s->bh, a));
+        mark(s, EXCHANGE);
     } else if (phase == 1) {
         mark(s, 1);
         NB_TRY(bh_cells_middle(s->stream, s->bh, a, s->cells_levels, 0));
         mark(s, 2);
         NB_TRY(bh_cells_middle(s->stream, s->bh, a, s->cells_levels, 1));
-        mark(s, 3);
         mark(s, 4);
         NB_TRY(bh_cells_middle(s->stream, s->bh, a, s->cells_levels, 2));
+        mark(s, EXCHANGE);
     } else {
+        mark(s, 3);
+        NB_TRY(bh_cells_end(s->stream, s->bh, a, s->cells_levels, 0));
         mark(s, 5);
-        NB_TRY(bh_cells_end(s->stream, s->bh, a, s->cells_levels));
-        mark(s, 6);
+        NB_TRY(bh_cells_end(s->stream, s->bh, a, s->cells_levels, 1));
+        mark(s, StageTimer::STAGE_END);
         s->first_kick = false;
         s->stepped = true;
         s->cells_steps += 1;
@@ -719,7 +723,7 @@ int nb_step_distributed(nb_sim *s, int nsteps)
         // before and after: the host does not wait
         double2 *buf = s->alg == NB_ALG_DIRECT ? s->pos2 : s->pos;
         NB_TRY(comm_all_gather_f64(s->comm, (double *)buf, 2 * s->chunk, s->stream));
-        mark(s, s->alg == NB_ALG_DIRECT ? 2 : 7);
+        mark(s, StageTimer::STAGE_END);
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
         if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= refresh_interval(s->n)) {
@@ -893,14 +897,14 @@ int nb_set_stage_timing(nb_sim *s, int on)
     if (!s)
         return fail(NB_ERR_ARG, "nb_set_stage_timing: sim is NULL");
     s->collect_stats = (on & 2) ? 1 : 0;
-    return s->timer.set(s->stream, s->alg == NB_ALG_DIRECT, on & 1);
+    return s->timer.set(s->stream, on & 1);
 }
 
 int nb_stage_ms(nb_sim *s, float *out, int count)
 {
     if (!s || !out)
         return fail(NB_ERR_ARG, "nb_stage_ms: NULL argument");
-    return s->timer.read(s->stream, s->alg == NB_ALG_DIRECT, out, count);
+    return s->timer.read(s->stream, out, count);
 }
 
 int nb_debug_read(nb_sim *s, int which, void *out, size_t bytes, size_t *written)

@@ -153,10 +153,10 @@ int step_local(nb_sim3 *s, int do_integrate)
     if (s->alg == NB_ALG_DIRECT) {
         s->ds.pos_cur = s->pos;
         s->ds.pos_next = s->pos2;
-        mark(s, 0);
+        mark(s, 5);
         NB_TRY(direct3_step(s->stream, s->ds, s->n, s->t0, s->t1 - s->t0, s->fc, integrate_args(s, do_integrate),
                             s->p.collision_th));
-        mark(s, 1);
+        mark(s, 6);
         return NB_OK;
     }
     Bh3StepArgs a;
@@ -208,7 +208,7 @@ int step_finish(nb_sim3 *s)
     return NB_OK;
 }
 
-int collect_timing(nb_sim3 *s) { return s->timer.step_done(s->stream, s->alg == NB_ALG_DIRECT); }
+int collect_timing(nb_sim3 *s) { return s->timer.step_done(s->stream); }
 
 void release(nb_sim3 *s)
 {
@@ -550,7 +550,7 @@ int nb3_step_distributed(nb_sim3 *s, int nsteps)
         NB_TRY(step_local(s, 1));
         double *buf = s->alg == NB_ALG_DIRECT ? s->pos2 : s->pos;
         NB_TRY(comm_all_gather_f64(s->comm, buf, 3 * s->chunk, s->stream));
-        mark(s, s->alg == NB_ALG_DIRECT ? 2 : 7);
+        mark(s, StageTimer::STAGE_END);
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
         if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= refresh_interval(s->n)) {
@@ -726,14 +726,14 @@ int nb3_set_stage_timing(nb_sim3 *s, int on)
     if (!s)
         return fail(NB_ERR_ARG, "nb3_set_stage_timing: sim is NULL");
     s->collect_stats = (on & 2) ? 1 : 0;
-    return s->timer.set(s->stream, s->alg == NB_ALG_DIRECT, on & 1);
+    return s->timer.set(s->stream, on & 1);
 }
 
 int nb3_stage_ms(nb_sim3 *s, float *out, int count)
 {
     if (!s || !out)
         return fail(NB_ERR_ARG, "nb3_stage_ms: NULL argument");
-    return s->timer.read(s->stream, s->alg == NB_ALG_DIRECT, out, count);
+    return s->timer.read(s->stream, out, count);
 }
 
 int nb3_debug_read(nb_sim3 *s, int which, void *out, size_t bytes, size_t *written)

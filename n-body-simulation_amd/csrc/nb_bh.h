@@ -96,10 +96,12 @@ struct BhStepArgs {
 // Stable LSD radix sort of (key, index) pairs by key << 2, ping-pong between the two buffers;
 // the result is in buffer 0.  cut[2] = first pass with work (sort_first_pass in nb_dev.h); the
 // unsorted pairs must be in buffer cut[2] & 1.  hist: sort_hist_words(n) words, totals: 256.
+// first_launch: passes below it are not even launched -- only for a caller that chose the key width
+// itself and so knows that cut[2] >= first_launch; 0 launches all eight (the device decides).
 int sort_blocks(int n);
 size_t sort_hist_words(int n);
 int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], int n, const uint32_t *cut, uint32_t *hist,
-               uint32_t *totals);
+               uint32_t *totals, int first_launch = 0);
 // Level-by-level tree over sorted keys whose digits (bits = 2: quadtree, 3: octree) start at bit
 // 61.  node_meta: {first body, count, first child, child count | cell level << 8}; split:
 // (n + 256) * build_split_bytes(bits) bytes; level_start: BH_MAX_DEPTH + 2 words; bsum:
@@ -136,6 +138,6 @@ size_t cells_agg_doubles(int cells_levels);
 int closed_level_for(double w0, double h0, double theta, double cth);
 int bh_cells_begin(hipStream_t s, BhBuffers &b, const BhStepArgs &a);
 int bh_cells_middle(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_levels, int part);
-int bh_cells_end(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_levels);
+int bh_cells_end(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_levels, int part);
 
 }  // namespace nb

@@ -530,10 +530,12 @@ int sort_blocks(int n) { return (n + SORT_TILE - 1) / SORT_TILE; }
 size_t sort_hist_words(int n) { return (size_t)SORT_BINS * sort_blocks(n); }
 
 int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], int n, const uint32_t *cut, uint32_t *hist,
-               uint32_t *totals)
+               uint32_t *totals, int first_launch)
 {
     const int nblk = sort_blocks(n);
-    for (int pass = 0; pass < SORT_PASSES; ++pass) {
+    // first_launch > 0: the caller KNOWS cut[2] >= first_launch (it chose the key width itself); the
+    // passes below it would return at once, at a launch each
+    for (int pass = first_launch; pass < SORT_PASSES; ++pass) {
         const int in = pass & 1, out = in ^ 1;
         hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, s, keys[in], n, pass, cut, hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(SORT_BINS), dim3(256), 0, s, hist, nblk, totals, pass, cut);
@@ -1954,22 +1956,30 @@ __device__ __forceinline__ float force_scale(float d2, float nm, float eps2, flo
     return ((rinv * rinv) * rinv) * nm;  // one dependent chain: as two products the compiler packs them, at a loss
 }
 
+// Waves per block.  The waves of a block share nothing, and a block's slot on its CU is free again
+// only when its slowest wave is done: one wave per block packs the CUs best (traversal at N = 5 M:
+// 1.00 ms with four, 0.99 with two, 0.97 with one).
+#ifndef NB_TR_WPB
+#define NB_TR_WPB 1
+#endif
+constexpr int TR_WPB = NB_TR_WPB;
+
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(256) void k_bh_force(ForceArgs a)
+__global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bh_force(ForceArgs a)
 {
-    __shared__ uint32_t st_node[4][TR_STACK];
-    __shared__ uint64_t st_mask[4][TR_STACK];
+    __shared__ uint32_t st_node[TR_WPB][TR_STACK];
+    __shared__ uint64_t st_mask[TR_WPB][TR_STACK];
     // the batch being visited: per entry {record} and {lane mask, child word, prune threshold}
-    __shared__ __attribute__((aligned(16))) uint4 st_batch[4][TR_BATCH][2];
+    __shared__ __attribute__((aligned(16))) uint4 st_batch[TR_WPB][TR_BATCH][2];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     uint32_t *snode = st_node[w];
     uint64_t *smask = st_mask[w];
     uint4(*batch)[2] = st_batch[w];
 
     const int ntarget = a.tlist ? (int)*a.tcount : a.n;
-    const int slot = (blockIdx.x * 4 + w) * 64 + lane;
+    const int slot = (blockIdx.x * TR_WPB + w) * 64 + lane;
     const bool valid = slot < ntarget;
-    if ((blockIdx.x * 4 + w) * 64 >= ntarget)
+    if ((blockIdx.x * TR_WPB + w) * 64 >= ntarget)
         return;  // whole wave idle (no block barriers below)
     const int k = valid ? (a.tlist ? (int)a.tlist[slot] : slot) : 0;
     const uint32_t body = a.idx[k];
@@ -2405,24 +2415,24 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     f.fc = a.fc;
     f.ia = a.ia;
     const int waves = (ntarget + 63) / 64;
-    dim3 grid((waves + 3) / 4);
+    dim3 grid((waves + TR_WPB - 1) / TR_WPB);
     if (ntarget <= 0)
         return NB_OK;
     const int mode = a.fc.exact_denom ? FM_EXACT : (a.fc.eps2_negligible ? FM_NOEPS : FM_EPS);
     if (a.collect_stats) {
         if (mode == FM_EXACT)
-            hipLaunchKernelGGL((k_bh_force<FM_EXACT, true>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh_force<FM_EXACT, true>), grid, dim3(64 * TR_WPB), 0, s, f);
         else if (mode == FM_EPS)
-            hipLaunchKernelGGL((k_bh_force<FM_EPS, true>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh_force<FM_EPS, true>), grid, dim3(64 * TR_WPB), 0, s, f);
         else
-            hipLaunchKernelGGL((k_bh_force<FM_NOEPS, true>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh_force<FM_NOEPS, true>), grid, dim3(64 * TR_WPB), 0, s, f);
     } else {
         if (mode == FM_EXACT)
-            hipLaunchKernelGGL((k_bh_force<FM_EXACT, false>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh_force<FM_EXACT, false>), grid, dim3(64 * TR_WPB), 0, s, f);
         else if (mode == FM_EPS)
-            hipLaunchKernelGGL((k_bh_force<FM_EPS, false>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh_force<FM_EPS, false>), grid, dim3(64 * TR_WPB), 0, s, f);
         else
-            hipLaunchKernelGGL((k_bh_force<FM_NOEPS, false>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh_force<FM_NOEPS, false>), grid, dim3(64 * TR_WPB), 0, s, f);
     }
     NB_HIP(hipGetLastError());
     return NB_OK;
@@ -2499,7 +2509,9 @@ int bh_cells_middle(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_
         return a.n > 0 ? bh_keys(s, b, a) : (int)NB_OK;
     }
     if (part == 1)
-        return a.n > 0 ? sort_pairs(s, b.keys, b.idx, a.n, b.cut, b.hist, b.hist_totals) : (int)NB_OK;
+        // the keys have exactly cells_levels digits (k_bbox_final): the passes with work are known here
+        return a.n > 0 ? sort_pairs(s, b.keys, b.idx, a.n, b.cut, b.hist, b.hist_totals, sort_first_pass(2 * cells_levels))
+                       : (int)NB_OK;
     const ComArgs c = com_args(b, a);
     if (a.n > 0) {
         hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[0], b.idx[0], a.n, a.pos,
@@ -2515,15 +2527,18 @@ int bh_cells_middle(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_
     return NB_OK;
 }
 
-int bh_cells_end(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_levels)
+// part 0: the tree from the reduced cell records, 1: traversal and integration.
+int bh_cells_end(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_levels, int part)
 {
+    if (part == 1)
+        return bh_force(s, b, a);
     const ComArgs c = com_args(b, a);
     const dim3 grid(1u << (2 * pyr_split(cells_levels)));
     hipLaunchKernelGGL(k_pyr_sub<true>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range, b.agg);
     hipLaunchKernelGGL(k_pyr_top, dim3(1), dim3(256), 0, s, c, b.node_meta, b.level_start, b.counters, b.keys[0],
                        (Split<2> *)b.split, b.bsum, a.n, b.levels_host, b.chunk_info);
     NB_HIP(hipGetLastError());
-    return bh_force(s, b, a);
+    return NB_OK;
 }
 
 // ------------------------------------------------------------------ buffers

@@ -517,14 +517,19 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+#ifndef NB_TR3_WPB
+#define NB_TR3_WPB 1
+#endif
+constexpr int TR3_WPB = NB_TR3_WPB;  // waves per block: they share nothing, one per block packs the CUs best (7.27 -> 6.97 ms)
+
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
+__global__ __launch_bounds__(64 * TR3_WPB) void k_bh3_force(Force3Args a)
 {
-    __shared__ uint32_t st_node[4][TR3_STACK];
-    __shared__ uint64_t st_mask[4][TR3_STACK];
+    __shared__ uint32_t st_node[TR3_WPB][TR3_STACK];
+    __shared__ uint64_t st_mask[TR3_WPB][TR3_STACK];
     // the batch being visited: per entry {record}, {lane mask, opening threshold, child word}
-    __shared__ __attribute__((aligned(16))) uint4 st_batch[4][TR3_BATCH][2];
-    __shared__ float st_prune[4][TR3_BATCH];
+    __shared__ __attribute__((aligned(16))) uint4 st_batch[TR3_WPB][TR3_BATCH][2];
+    __shared__ float st_prune[TR3_WPB][TR3_BATCH];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     uint32_t *snode = st_node[w];
     uint64_t *smask = st_mask[w];
@@ -532,8 +537,8 @@ __global__ __launch_bounds__(256) void k_bh3_force(Force3Args a)
     float *bprune = st_prune[w];
 
     const int ntarget = a.tlist ? (int)*a.tcount : a.n;
-    const int slot = (blockIdx.x * 4 + w) * 64 + lane;
-    if ((blockIdx.x * 4 + w) * 64 >= ntarget)
+    const int slot = (blockIdx.x * TR3_WPB + w) * 64 + lane;
+    if ((blockIdx.x * TR3_WPB + w) * 64 >= ntarget)
         return;  // whole wave idle (no block barriers below)
     const bool valid = slot < ntarget;
     const int last = valid ? slot : ntarget - 1;
@@ -883,22 +888,22 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     f.theta = a.theta;
     f.collision_th = a.collision_th;
     const int waves = (ntarget + 63) / 64;
-    const dim3 grid((waves + 3) / 4);
+    const dim3 grid((waves + TR3_WPB - 1) / TR3_WPB);
     const int mode = a.fc.exact_denom ? F3_EXACT : (a.fc.eps2_negligible ? F3_NOEPS : F3_EPS);
     if (a.collect_stats) {
         if (mode == F3_EXACT)
-            hipLaunchKernelGGL((k_bh3_force<F3_EXACT, true>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh3_force<F3_EXACT, true>), grid, dim3(64 * TR3_WPB), 0, s, f);
         else if (mode == F3_EPS)
-            hipLaunchKernelGGL((k_bh3_force<F3_EPS, true>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh3_force<F3_EPS, true>), grid, dim3(64 * TR3_WPB), 0, s, f);
         else
-            hipLaunchKernelGGL((k_bh3_force<F3_NOEPS, true>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh3_force<F3_NOEPS, true>), grid, dim3(64 * TR3_WPB), 0, s, f);
     } else {
         if (mode == F3_EXACT)
-            hipLaunchKernelGGL((k_bh3_force<F3_EXACT, false>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh3_force<F3_EXACT, false>), grid, dim3(64 * TR3_WPB), 0, s, f);
         else if (mode == F3_EPS)
-            hipLaunchKernelGGL((k_bh3_force<F3_EPS, false>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh3_force<F3_EPS, false>), grid, dim3(64 * TR3_WPB), 0, s, f);
         else
-            hipLaunchKernelGGL((k_bh3_force<F3_NOEPS, false>), grid, dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_bh3_force<F3_NOEPS, false>), grid, dim3(64 * TR3_WPB), 0, s, f);
     }
     NB_HIP(hipGetLastError());
     return NB_OK;

@@ -207,7 +207,7 @@ int refresh_sort(hipStream_t s, RefreshBuffers &r, const double *pos, int dims, 
     }
     NB_HIP(hipGetLastError());
     r.origin_set = true;
-    return sort_pairs(s, r.keys, r.idx, n, r.cut, r.hist, r.totals);  // result in buffer 0
+    return sort_pairs(s, r.keys, r.idx, n, r.cut, r.hist, r.totals, 4);  // passes 4..7 (k_rf_box's cut[2]); result in buffer 0
 }
 
 int refresh_gather(hipStream_t s, RefreshBuffers &r, void *array, size_t elem_bytes, int n)

@@ -65,13 +65,81 @@ def run3(alg, scenario, n, steps, thickness, warm=2):
     print("%-22s N=%-9d thick %.0e %9.3f ms/step  %s" % (name, n, thickness, dt * 1e3, extra), flush=True)
 
 
+def ranks(world, n, steps, cells, scenario=2):
+    """Per-rank GPU time of a run cut over `world` ranks, measured with `world` handles on this one
+    GPU (the collectives are done through the host between the parts of a step and are not timed):
+    what each rank's kernels cost, stage by stage, rank 0 and the slowest rank."""
+    import test_gpu_partition_edge as pe
+
+    hip = pe._hip()
+    b = nb.init_scenario(scenario, n, 12345)
+    sims = [nb.NBodySim(n, nb.BARNES_HUT) for _ in range(world)]
+    try:
+        for r, s in enumerate(sims):
+            s.set_bodies(b)
+            s.set_partition(r, world)
+            if cells:
+                s.set_exchange(nb.EXCHANGE_CELLS)
+
+        def step():
+            if cells:
+                for part, op in ((0, np.maximum), (1, np.add)):
+                    for s in sims:
+                        s.step_cells(part)
+                        s.sync()  # one rank's kernels at a time: they would share the GPU otherwise
+                    pe.reduce_between_ranks(hip, sims, part, op)
+                for s in sims:
+                    s.step_cells(2)
+                    s.sync()
+            else:
+                for s in sims:
+                    s.step_local()
+                    s.sync()
+                bufs = [s.exchange_buffer() for s in sims]
+                chunk, rb = bufs[0][1], bufs[0][2]
+                for src in range(world):
+                    lo, hi = min(n, src * chunk), min(n, (src + 1) * chunk)
+                    for dst in range(world):
+                        if dst != src and hi > lo:
+                            assert hip.hipMemcpy(bufs[dst][0] + lo * rb, bufs[src][0] + lo * rb, (hi - lo) * rb, 3) == 0
+                assert hip.hipDeviceSynchronize() == 0
+                for s in sims:
+                    s.step_finish()
+
+        for _ in range(3):
+            step()
+        for s in sims:
+            s.sync()
+            s.set_stage_timing(True, counters=False)
+        for _ in range(steps):
+            step()
+        for s in sims:
+            s.sync()
+        per = [s.stage_ms() for s in sims]
+    finally:
+        for s in sims:
+            s.close()
+    tot = [sum(v for k, v in st.items() if k != "exchange") for st in per]
+    worst = int(np.argmax(tot))
+    fmt = lambda st: " ".join("%s=%.3f" % kv for kv in st.items() if kv[1] > 0)  # noqa: E731
+    print("BH %s N=%d world=%d %s: rank 0 %.3f ms [%s]; slowest rank %d %.3f ms [%s]" % (
+        {0: "spiral", 2: "collision"}[scenario], n, world, "cell exchange" if cells else "position exchange",
+        tot[0], fmt(per[0]), worst, tot[worst], fmt(per[worst])), flush=True)
+
+
 which = sys.argv[1:] or ["c2", "c3", "c4", "c5"]
+if "ranks" in which:
+    for world in (2, 4, 8):
+        ranks(world, 5000000, 5, True)
+        ranks(world, 5000000, 5, False)
 if "d3" in which:
     run3(nb.DIRECT, nb.SPIRAL, 65536, 20, 5.0e10)
     run3(nb.BARNES_HUT, nb.SPIRAL, 1000000, 10, 5.0e10)
     run3(nb.BARNES_HUT, nb.COLLISION, 5000000, 10, 2.0e10)
     run3(nb.BARNES_HUT, nb.COLLISION, 5000000, 10, 1.0e11)
     run3(nb.DIRECT, nb.SPIRAL, 1000000, 3, 5.0e10, 1)
+if "d3c" in which:
+    run3(nb.BARNES_HUT, nb.COLLISION, 5000000, 10, 2.0e10)
 if "c2" in which:
     run(nb.DIRECT, nb.SPIRAL, 65536, 20)
 if "c3" in which:
