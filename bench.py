@@ -71,7 +71,7 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
         eng = GpuEngine(sim, device)
         stepper = DistributedSim(eng)
         if cells:
-            eng.use_cell_exchange()
+            eng.use_cell_exchange(nb.EXCHANGE_AUTO)
         step = lambda: stepper.update(1)  # noqa: E731
     elif world > 1:
         # the library's own communicator: the step's collectives (one in-place ncclAllGather of the
@@ -90,7 +90,7 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
             try:
                 sim.comm_init(rank, world, cid[0])
                 if cells:
-                    sim.set_exchange(nb.EXCHANGE_CELLS)
+                    sim.set_exchange(nb.EXCHANGE_AUTO)
             except nb.NBodyError as e:
                 ok = 0
                 print("bench.py: rank %d: %s" % (rank, e), file=sys.stderr)
@@ -109,7 +109,7 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
             eng = GpuEngine(sim, device)
             stepper = DistributedSim(eng)
             if cells:
-                eng.use_cell_exchange()
+                eng.use_cell_exchange(nb.EXCHANGE_AUTO)
             step = lambda: stepper.update(1)  # noqa: E731
     else:
         step = lambda: sim.update(1)  # noqa: E731
@@ -159,6 +159,7 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ldt = float(t.item())
         late = {"at_step": late_at, "ms_per_step": ldt * 1e3 / steps, "stage_ms": lstages}
+    barrier_sync(world)  # every rank's last collectives are done before the communicator goes
     sim.close()
     return dt, stages, counters, late
 

@@ -191,15 +191,27 @@ int nb_step_distributed(nb_sim *sim, int nsteps);
  * bodies, so nb_read_bodies all-gathers the positions first when the library holds the communicator
  * (a collective call then) and returns only this rank's velocities up to date.  Needs a tree that
  * closes at level <= 10, Euler integration and bucket_depth 0; switch it on after nb_set_partition /
- * nb_comm_init and before the first step.  Every 16 steps the host waits for the stream once.
+ * nb_comm_init and before the first step.
+ * The level follows the bounding box: every 16 steps the host waits for the stream once and looks at
+ * the box of the last step (the same on every rank).  A box that has grown so far that the tree
+ * closes below level 10 SUSPENDS the cell exchange -- the ranks all-gather their positions once and
+ * step by the position exchange -- until the box allows it again.
+ * NB_EXCHANGE_AUTO: the same, and the cell exchange is also suspended while its records are more
+ * data than the positions (twice 64 bytes x 4^level against 16 bytes x n).
  *
- * With nb_comm_init, nb_step_distributed does all of this.  With another collective:
- *   nb_step_cells(sim, 0); reduce nb_cells_buffer(sim, 0, ..) over the ranks with MAX, in place;
- *   nb_step_cells(sim, 1); reduce nb_cells_buffer(sim, 1, ..) over the ranks with SUM, in place;
- *   nb_step_cells(sim, 2);
- * (buffers of doubles; ask for buffer 1 after part 1 of each step: its length follows the box). */
-enum nb_exchange { NB_EXCHANGE_POSITIONS = 0, NB_EXCHANGE_CELLS = 1 };
+ * With nb_comm_init, nb_step_distributed does all of this.  With another collective, per step:
+ *   nb_cells_level(sim, &level, &gather);
+ *   if (gather) all-gather nb_exchange_buffer over the ranks   (the cell exchange was suspended just now)
+ *   if (level < 0) { nb_step_local; all-gather nb_exchange_buffer; nb_step_finish; }   (suspended)
+ *   else {
+ *     nb_step_cells(sim, 0); reduce nb_cells_buffer(sim, 0, ..) over the ranks with MAX, in place;
+ *     nb_step_cells(sim, 1); reduce nb_cells_buffer(sim, 1, ..) over the ranks with SUM, in place;
+ *     nb_step_cells(sim, 2); }
+ * (buffers of doubles; ask for buffer 1 after part 1 of each step: its length follows the level).
+ * nb_step_cells(sim, 0) fails with NB_ERR_STATE while the cell exchange is suspended. */
+enum nb_exchange { NB_EXCHANGE_POSITIONS = 0, NB_EXCHANGE_CELLS = 1, NB_EXCHANGE_AUTO = 2 };
 int nb_set_exchange(nb_sim *sim, int mode);
+int nb_cells_level(nb_sim *sim, int *level, int *gather_positions_first);
 int nb_step_cells(nb_sim *sim, int part);
 int nb_cells_buffer(nb_sim *sim, int which, void **device_ptr, size_t *count_doubles);
 

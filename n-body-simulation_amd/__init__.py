@@ -27,7 +27,7 @@ LIB_PATH = os.environ.get("NBODY_HIP_LIB") or os.path.join(_HERE, "libnbody_hip.
 DIRECT, BARNES_HUT = 0, 1
 SPIRAL, RANDOM, COLLISION, SOLAR = 0, 1, 2, 3
 EULER, LEAPFROG = 0, 1
-EXCHANGE_POSITIONS, EXCHANGE_CELLS = 0, 1
+EXCHANGE_POSITIONS, EXCHANGE_CELLS, EXCHANGE_AUTO = 0, 1, 2
 
 # Same 72-byte layout as the reference's Body.
 BODY_DTYPE = np.dtype(
@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "nb_step", "nb_compute_accel", "nb_read_bodies", "nb_sync", "nb_set_stream", "nb_set_partition",
     "nb_exchange_buffer", "nb_step_local", "nb_step_finish", "nb_debug_read", "nb_set_stage_timing",
     "nb_stage_ms", "nb_diagnostics", "nb_refresh_order", "nb_compute_accel_static", "nb_comm_unique_id", "nb_comm_init", "nb_step_distributed",
-    "nb_velocity_buffer", "nb_set_exchange", "nb_step_cells", "nb_cells_buffer", "nb3_comm_init", "nb3_step_distributed", "nb3_refresh_order", "nb3_velocity_buffer", "nb_last_error", "nb_version",
+    "nb_velocity_buffer", "nb_set_exchange", "nb_cells_level", "nb_step_cells", "nb_cells_buffer", "nb3_comm_init", "nb3_step_distributed", "nb3_refresh_order", "nb3_velocity_buffer", "nb_last_error", "nb_version",
     "nb3_init_scenario", "nb3_create", "nb3_destroy", "nb3_setup", "nb3_set_bodies", "nb3_step",
     "nb3_compute_accel", "nb3_read_bodies", "nb3_sync", "nb3_debug_read", "nb3_set_stage_timing", "nb3_stage_ms",
     "nb3_diagnostics", "nb3_set_stream", "nb3_set_partition", "nb3_exchange_buffer", "nb3_step_local", "nb3_step_finish",
@@ -131,6 +131,7 @@ def load_library(path=None):
     lib.nb3_refresh_order.argtypes = [vp]
     lib.nb_set_exchange.argtypes = [vp, i]
     lib.nb_step_cells.argtypes = [vp, i]
+    lib.nb_cells_level.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     lib.nb_cells_buffer.argtypes = [vp, i, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.nb3_comm_init.argtypes = [vp, i, i, vp]
     lib.nb3_step_distributed.argtypes = [vp, i]
@@ -249,8 +250,16 @@ class NBodySim:
         return p.value, c.value, r.value
 
     def set_exchange(self, mode):
-        """What the ranks exchange each step: EXCHANGE_POSITIONS or EXCHANGE_CELLS (nb_set_exchange)."""
+        """What the ranks exchange each step: EXCHANGE_POSITIONS, EXCHANGE_CELLS or EXCHANGE_AUTO (nb_set_exchange)."""
         _check(self._lib.nb_set_exchange(self._h, mode))
+
+    def cells_level(self):
+        """Before a step with the cell exchange: (level of the cells to be exchanged, or -1 while it is
+        suspended and the step is a position-exchange step; whether the ranks must all-gather their
+        positions first because it was suspended just now)  (nb_cells_level)."""
+        lvl, gather = C.c_int(-1), C.c_int(0)
+        _check(self._lib.nb_cells_level(self._h, C.byref(lvl), C.byref(gather)))
+        return lvl.value, bool(gather.value)
 
     def step_cells(self, part):
         _check(self._lib.nb_step_cells(self._h, part))

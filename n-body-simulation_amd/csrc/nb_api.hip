@@ -188,6 +188,8 @@ int step_finish(nb_sim *s)
 {
     s->first_kick = false;
     s->stepped = true;
+    if (s->exchange != NB_EXCHANGE_POSITIONS)
+        s->cells_steps += 1;  // (the cell exchange is suspended: its level is still looked at every 16 steps)
     if (s->alg == NB_ALG_DIRECT) {
         // records of the bodies other ranks advanced come from the gathered positions
         if (s->world > 1) {
@@ -492,7 +494,7 @@ int nb_step_local(nb_sim *s)
         return fail(NB_ERR_STATE, "nb_step_local: no bodies were set");
     if (s->mid_step)
         return fail(NB_ERR_STATE, "nb_step_local: the previous step was not finished");
-    if (s->exchange == NB_EXCHANGE_CELLS)
+    if (s->cells_active)
         return fail(NB_ERR_STATE, "nb_step_local: with the cell exchange a step goes through nb_step_cells");
     NB_TRY(step_local(s, 1));
     s->mid_step = true;
@@ -556,28 +558,35 @@ static BhStepArgs cells_args(nb_sim *s, int do_integrate)
 
 // Digits for the keys of the coming steps, from the box of the last finished step (the caller has
 // waited for the stream, so every rank reads the same box): the level at which a box half as large
-// again would close the tree, so that the box may grow for a while.  -1: deeper than the dense
-// pyramid goes.
+// again would close the tree, so that the box may grow for a while.  -1: the positions are the
+// better thing to exchange -- the tree closes below the dense pyramid's last level, or
+// (NB_EXCHANGE_AUTO) the cell records, which an all-reduce moves about twice, are more data than
+// the positions an all-gather moves once.
 static int choose_cells_levels(nb_sim *s)
 {
     const double w = ((volatile double *)s->bh.hint_box)[0], h = ((volatile double *)s->bh.hint_box)[1];
     const int l = closed_level_for(1.5 * w, 1.5 * h, s->p.theta, s->p.collision_th);
-    return l <= cells_max_level() ? l : -1;
+    if (l > cells_max_level())
+        return -1;
+    if (s->exchange == NB_EXCHANGE_AUTO && 2 * cells_agg_doubles(l) * sizeof(double) > sizeof(double2) * (size_t)s->n)
+        return -1;
+    return l;
 }
 
 int nb_set_exchange(nb_sim *s, int mode)
 {
     if (!s)
         return fail(NB_ERR_ARG, "nb_set_exchange: sim is NULL");
-    if (mode != NB_EXCHANGE_POSITIONS && mode != NB_EXCHANGE_CELLS)
+    if (mode != NB_EXCHANGE_POSITIONS && mode != NB_EXCHANGE_CELLS && mode != NB_EXCHANGE_AUTO)
         return fail(NB_ERR_ARG, "nb_set_exchange: unknown mode");
     if (s->mid_step || s->cells_phase != 0)
         return fail(NB_ERR_STATE, "nb_set_exchange: a split step is in flight");
     if (mode == NB_EXCHANGE_POSITIONS) {
-        if (s->exchange == NB_EXCHANGE_CELLS && s->stepped)
+        if (s->cells_active && s->stepped)
             return fail(NB_ERR_STATE, "nb_set_exchange: after steps with the cell exchange this rank no longer holds the "
                                       "other ranks' positions; set the bodies again");
         s->exchange = mode;
+        s->cells_active = false;
         return NB_OK;
     }
     if (s->alg != NB_ALG_BARNES_HUT || s->p.bucket_depth != 0 || s->p.integrator != NB_INT_EULER)
@@ -588,30 +597,59 @@ int nb_set_exchange(nb_sim *s, int mode)
                                   "set and before the first step");
     NB_TRY(bh_cells_alloc(s->bh));
     NB_HIP(hipStreamSynchronize(s->stream));
+    const int before = s->exchange;
+    s->exchange = mode;
     const int levels = choose_cells_levels(s);
-    if (levels < 0)
+    if (levels < 0 && mode == NB_EXCHANGE_CELLS) {
+        s->exchange = before;
         return fail(NB_ERR_OVERFLOW, "nb_set_exchange: with these parameters the tree closes below level " +
                                          std::to_string(cells_max_level()) + "; use the position exchange");
+    }
     s->cells_levels = levels;
+    s->cells_active = levels >= 0;
     s->cells_steps = 0;
-    s->exchange = mode;
+    s->cells_checked = -1;
     return NB_OK;
 }
 
 // Every 16 steps the host waits for the stream and looks at the box the device left: the level of
-// the exchanged cells follows it (the same decision on every rank: the box is the reduced one).
-static int cells_housekeeping(nb_sim *s)
+// the exchanged cells follows it, and when the records of that level stop being the cheaper thing
+// to exchange (or the dense pyramid cannot hold the tree any more) the cell exchange is suspended
+// until they are again.  The decision is the same on every rank: the box is the reduced one, or,
+// while suspended, the box of all positions, which every rank holds.  *gather: the cell exchange
+// was suspended just now, so the ranks must all-gather their positions before the next step.
+static int cells_housekeeping(nb_sim *s, bool *gather)
 {
-    if (s->cells_steps == 0 || s->cells_steps % 16 != 0)
+    *gather = false;
+    if (s->exchange == NB_EXCHANGE_POSITIONS || s->cells_steps == 0 || s->cells_steps % 16 != 0 ||
+        s->cells_checked == s->cells_steps)
         return NB_OK;
+    s->cells_checked = s->cells_steps;
     NB_HIP(hipStreamSynchronize(s->stream));
-    if (*(volatile uint32_t *)s->bh.err_host != 0u)
+    if (s->cells_active && *(volatile uint32_t *)s->bh.err_host != 0u)
         return fail(NB_ERR_OVERFLOW, "cell exchange: the bounding box grew by more than half within 16 steps; the last "
                                      "steps' tree was cut above the level it closes at");
     const int levels = choose_cells_levels(s);
-    if (levels < 0)
-        return fail(NB_ERR_OVERFLOW, "cell exchange: the tree now closes below level " + std::to_string(cells_max_level()));
-    s->cells_levels = levels;
+    if (levels < 0) {
+        *gather = s->cells_active;
+        s->cells_active = false;
+    } else {
+        s->cells_levels = levels;
+        s->cells_active = true;
+    }
+    return NB_OK;
+}
+
+int nb_cells_level(nb_sim *s, int *level, int *gather_positions_first)
+{
+    if (!s || !level || !gather_positions_first)
+        return fail(NB_ERR_ARG, "nb_cells_level: NULL argument");
+    if (s->mid_step || s->cells_phase != 0)
+        return fail(NB_ERR_STATE, "nb_cells_level: a split step is in flight");
+    bool gather = false;
+    NB_TRY(cells_housekeeping(s, &gather));
+    *level = s->cells_active ? s->cells_levels : -1;
+    *gather_positions_first = gather ? 1 : 0;
     return NB_OK;
 }
 
@@ -619,7 +657,7 @@ int nb_cells_buffer(nb_sim *s, int which, void **device_ptr, size_t *count)
 {
     if (!s || !device_ptr || !count)
         return fail(NB_ERR_ARG, "nb_cells_buffer: NULL argument");
-    if (s->exchange != NB_EXCHANGE_CELLS)
+    if (!s->cells_active)
         return fail(NB_ERR_STATE, "nb_cells_buffer: the cell exchange is not switched on");
     if (which == 0) {
         *device_ptr = s->bh.red4;
@@ -636,14 +674,20 @@ int nb_step_cells(nb_sim *s, int phase)
 {
     if (!s)
         return fail(NB_ERR_ARG, "nb_step_cells: sim is NULL");
-    if (s->exchange != NB_EXCHANGE_CELLS)
+    if (s->exchange == NB_EXCHANGE_POSITIONS)
         return fail(NB_ERR_STATE, "nb_step_cells: the cell exchange is not switched on");
     if (phase != s->cells_phase)
         return fail(NB_ERR_STATE, "nb_step_cells: the parts of a step go 0, 1, 2");
+    if (phase == 0) {
+        bool gather = false;
+        NB_TRY(cells_housekeeping(s, &gather));
+        if (!s->cells_active)
+            return fail(NB_ERR_STATE, "nb_step_cells: the cell exchange is suspended (nb_cells_level says so before "
+                                      "a step): all-gather the positions and step with nb_step_local / nb_step_finish");
+    }
     const BhStepArgs a = cells_args(s, 1);
     constexpr int EXCHANGE = 6;  // the caller's collectives run between the parts
     if (phase == 0) {
-        NB_TRY(cells_housekeeping(s));
         mark(s, 0);
         NB_TRY(bh_cells_begin(s->stream, s->bh, a));
         mark(s, EXCHANGE);
@@ -701,23 +745,23 @@ int nb_step_distributed(nb_sim *s, int nsteps)
         return fail(NB_ERR_STATE, "nb_step_distributed: call nb_comm_init first");
     if (!s->have_bodies)
         return fail(NB_ERR_STATE, "nb_step_distributed: no bodies were set");
-    if (s->mid_step)
+    if (s->mid_step || s->cells_phase != 0)
         return fail(NB_ERR_STATE, "nb_step_distributed: a split step is in flight");
-    if (s->exchange == NB_EXCHANGE_CELLS) {
-        // two reductions per step instead of the gather of all positions: the ranks' extents (4
-        // doubles, maximum) and the records of the cells of the keys' last level (sum)
-        if (s->cells_phase != 0)
-            return fail(NB_ERR_STATE, "nb_step_distributed: a split step is in flight");
-        for (int k = 0; k < nsteps; ++k) {
+    for (int k = 0; k < nsteps; ++k) {
+        bool gather = false;
+        NB_TRY(cells_housekeeping(s, &gather));
+        if (gather)  // the cell exchange was suspended: from here on every rank holds all positions again
+            NB_TRY(comm_all_gather_f64(s->comm, (double *)s->pos, 2 * s->chunk, s->stream));
+        if (s->cells_active) {
+            // two reductions per step instead of the gather of all positions: the ranks' extents (4
+            // doubles, maximum) and the records of the cells of the keys' last level (sum)
             NB_TRY(nb_step_cells(s, 0));
             NB_TRY(comm_all_reduce_max_f64(s->comm, s->bh.red4, 4, s->stream));
             NB_TRY(nb_step_cells(s, 1));
             NB_TRY(comm_all_reduce_sum_f64(s->comm, s->bh.agg, cells_agg_doubles(s->cells_levels), s->stream));
             NB_TRY(nb_step_cells(s, 2));
+            continue;
         }
-        return NB_OK;
-    }
-    for (int k = 0; k < nsteps; ++k) {
         NB_TRY(step_local(s, 1));
         // the new positions of every rank's slice, in place, ordered on the stream with the kernels
         // before and after: the host does not wait
@@ -744,7 +788,7 @@ int nb_compute_accel(nb_sim *s)
         return fail(NB_ERR_STATE, "nb_compute_accel: no bodies were set");
     if (s->mid_step)
         return fail(NB_ERR_STATE, "nb_compute_accel: a split step is in flight");
-    if (s->exchange == NB_EXCHANGE_CELLS)
+    if (s->cells_active)
         return fail(NB_ERR_STATE, "nb_compute_accel: with the cell exchange this rank does not hold the other ranks' "
                                   "positions");
     NB_TRY(step_local(s, 0));
@@ -771,12 +815,12 @@ int nb_read_bodies(nb_sim *s, nb_body *out)
     std::vector<uint8_t> dyn(n);
     // leapfrog keeps velocities half a step behind the positions; bring them level with the
     // force at the current positions
-    if (s->exchange == NB_EXCHANGE_CELLS && s->cells_phase != 0)
+    if (s->cells_phase != 0)
         return fail(NB_ERR_STATE, "nb_read_bodies: a split step is in flight");
-    if (s->exchange == NB_EXCHANGE_CELLS && s->comm)  // the other ranks' positions (a collective call)
+    if (s->cells_active && s->comm)  // the other ranks' positions (a collective call)
         NB_TRY(comm_all_gather_f64(s->comm, (double *)s->pos, 2 * s->chunk, s->stream));
     const bool half_step = s->p.integrator == NB_INT_LEAPFROG && !s->first_kick && !s->mid_step &&
-                           s->exchange != NB_EXCHANGE_CELLS;
+                           s->exchange == NB_EXCHANGE_POSITIONS;
     if (half_step) {
         // this force evaluation is not a step: keep it out of the per-stage timing
         const int timing = s->timer.on;

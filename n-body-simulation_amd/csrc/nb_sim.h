@@ -47,7 +47,9 @@ struct nb_sim {
     nb::Comm *comm = nullptr;  // RCCL communicator of nb_comm_init (null: none)
     int exchange = 0;          // nb_exchange: what the ranks exchange each step
     int cells_levels = -1;     // cell exchange: digits of the keys (the same on every rank)
+    bool cells_active = false; // cell exchange: in use for the coming steps (else suspended: positions are exchanged)
     long cells_steps = 0;      // cell exchange: steps since it was switched on
+    long cells_checked = -1;   // cell exchange: the step count at which the level was last looked at
     int cells_phase = 0;       // cell exchange by hand: the next part of the step (0, 1, 2)
 
     // direct sum

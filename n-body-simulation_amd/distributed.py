@@ -55,11 +55,12 @@ class GpuEngine:
         self.sim.set_partition(rank, world)
         self.world = world
 
-    def use_cell_exchange(self):
-        """Switches the simulation to NB_EXCHANGE_CELLS (after set_partition, before the first step)."""
+    def use_cell_exchange(self, mode=None):
+        """Switches the simulation to NB_EXCHANGE_CELLS (or NB_EXCHANGE_AUTO) after set_partition and
+        before the first step."""
         from . import EXCHANGE_CELLS
 
-        self.sim.set_exchange(EXCHANGE_CELLS)
+        self.sim.set_exchange(EXCHANGE_CELLS if mode is None else mode)
         self.cells = True
 
     def step_local(self):
@@ -121,7 +122,14 @@ class DistributedSim:
     def update(self, nsteps=1):
         cells = getattr(self.engine, "cells", False)
         for _ in range(nsteps):
+            level = -1
             if cells:
+                # the library follows the bounding box and suspends the cell exchange when the
+                # positions are the cheaper (or the only possible) thing to exchange
+                level, gather = self.engine.sim.cells_level()
+                if gather:
+                    self.all_gather_positions()
+            if level >= 0:
                 self.engine.sim.step_cells(0)
                 self.all_reduce_cells(0)
                 self.engine.sim.step_cells(1)

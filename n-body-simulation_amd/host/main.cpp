@@ -332,9 +332,10 @@ int main(int argc, char **argv)
     nb.setup(scenario);
     if (gpus > 1) {
         nb.commInit(rank, gpus, comm_id);
-        // every rank takes the same decision: it depends on the parameters and the bodies only
+        // (cell records while they are less data than the positions and the tree closes within the
+        // levels they can be exchanged at; the library follows the bounding box and switches by itself)
         if (alg == NB_ALG_BARNES_HUT && exchange_cells && integrator == NB_INT_EULER &&
-            nb_set_exchange(nb.handle(), NB_EXCHANGE_CELLS) != NB_OK && !quiet)
+            nb_set_exchange(nb.handle(), NB_EXCHANGE_AUTO) != NB_OK && !quiet)
             std::cout << "note: " << nb_last_error() << "; exchanging positions" << std::endl;
     }
     auto print_energy = [&](const char *when) {

@@ -79,10 +79,31 @@ def ranks(world, n, steps, cells, scenario=2):
             s.set_bodies(b)
             s.set_partition(r, world)
             if cells:
-                s.set_exchange(nb.EXCHANGE_CELLS)
+                s.set_exchange(cells)
+
+        def gather_positions():
+            bufs = [s.exchange_buffer() for s in sims]
+            chunk, rb = bufs[0][1], bufs[0][2]
+            for src in range(world):
+                lo, hi = min(n, src * chunk), min(n, (src + 1) * chunk)
+                for dst in range(world):
+                    if dst != src and hi > lo:
+                        assert hip.hipMemcpy(bufs[dst][0] + lo * rb, bufs[src][0] + lo * rb, (hi - lo) * rb, 3) == 0
+            assert hip.hipDeviceSynchronize() == 0
 
         def step():
+            level = -1
             if cells:
+                said = [s.cells_level() for s in sims]
+                assert all(x == said[0] for x in said), said
+                level, gather = said[0]
+                if gather:
+                    gather_positions()
+                if level != step.level:
+                    print("  step %d: cell level %d -> %d" % (step.count, step.level, level), flush=True)
+                    step.level = level
+            step.count += 1
+            if level >= 0:
                 for part, op in ((0, np.maximum), (1, np.add)):
                     for s in sims:
                         s.step_cells(part)
@@ -95,16 +116,11 @@ def ranks(world, n, steps, cells, scenario=2):
                 for s in sims:
                     s.step_local()
                     s.sync()
-                bufs = [s.exchange_buffer() for s in sims]
-                chunk, rb = bufs[0][1], bufs[0][2]
-                for src in range(world):
-                    lo, hi = min(n, src * chunk), min(n, (src + 1) * chunk)
-                    for dst in range(world):
-                        if dst != src and hi > lo:
-                            assert hip.hipMemcpy(bufs[dst][0] + lo * rb, bufs[src][0] + lo * rb, (hi - lo) * rb, 3) == 0
-                assert hip.hipDeviceSynchronize() == 0
+                gather_positions()
                 for s in sims:
                     s.step_finish()
+
+        step.level, step.count = -2, 0
 
         for _ in range(3):
             step()
@@ -123,15 +139,21 @@ def ranks(world, n, steps, cells, scenario=2):
     worst = int(np.argmax(tot))
     fmt = lambda st: " ".join("%s=%.3f" % kv for kv in st.items() if kv[1] > 0)  # noqa: E731
     print("BH %s N=%d world=%d %s: rank 0 %.3f ms [%s]; slowest rank %d %.3f ms [%s]" % (
-        {0: "spiral", 2: "collision"}[scenario], n, world, "cell exchange" if cells else "position exchange",
+        {0: "spiral", 2: "collision"}[scenario], n, world,
+        {0: "position exchange", 1: "cell exchange", 2: "cell exchange (auto)"}[int(cells)],
         tot[0], fmt(per[0]), worst, tot[worst], fmt(per[worst])), flush=True)
 
 
 which = sys.argv[1:] or ["c2", "c3", "c4", "c5"]
+if "cells_long" in which:
+    # the cell exchange over the stretch bench.py's late-state leg covers: the level of the exchanged
+    # cells must keep up with the box (an error from nb_step_cells otherwise)
+    ranks(2, 5000000, 330, nb.EXCHANGE_CELLS)
+    ranks(2, 5000000, 330, nb.EXCHANGE_AUTO)
 if "ranks" in which:
     for world in (2, 4, 8):
-        ranks(world, 5000000, 5, True)
-        ranks(world, 5000000, 5, False)
+        ranks(world, 5000000, 5, nb.EXCHANGE_CELLS)
+        ranks(world, 5000000, 5, nb.EXCHANGE_POSITIONS)
 if "d3" in which:
     run3(nb.DIRECT, nb.SPIRAL, 65536, 20, 5.0e10)
     run3(nb.BARNES_HUT, nb.SPIRAL, 1000000, 10, 5.0e10)

@@ -144,6 +144,32 @@ def test_native_rccl_world1_cell_exchange(nb, oracle):
     assert ms["force"] > 0
 
 
+def test_native_rccl_world1_cell_exchange_suspends_and_goes_on(nb):
+    """nb_step_distributed over a run in which a body leaving at speed makes the box outgrow the cell
+    exchange: the library gathers the positions (ncclAllGather) and goes on with the position
+    exchange by itself.  Checked against the plain run; `levels` shows that the switch happened."""
+    n, steps = 3001, 200
+    b = nb.init_scenario(nb.SPIRAL, n, 21)
+    extent = np.abs(b["pos"]).max()
+    k = int(np.argmax(np.abs(b["pos"][:, 0])))
+    b["vel"][k] = (np.sign(b["pos"][k, 0]) * 0.04 * extent / nb.default_params().dt, 0.0)
+    with nb.NBodySim(n, nb.BARNES_HUT) as plain, nb.NBodySim(n, nb.BARNES_HUT) as part:
+        plain.set_bodies(b)
+        part.set_bodies(b)
+        part.comm_init(0, 1, nb.comm_unique_id())
+        part.set_exchange(nb.EXCHANGE_CELLS)
+        first = part.cells_level()
+        plain.update(steps)
+        part.step_distributed(steps)
+        last = part.cells_level()
+        a = part.read_bodies()
+        ref = plain.read_bodies()
+    assert first[0] >= 0 and last == (-1, False)
+    # (FP32 sums in another order over 200 steps: 3e-7 of the extent observed)
+    assert np.linalg.norm(a["pos"] - ref["pos"], axis=1).max() <= 3e-6 * np.abs(ref["pos"]).max()
+    assert np.linalg.norm(a["vel"] - ref["vel"], axis=1).max() <= 5.0
+
+
 @pytest.mark.parametrize("alg,dims,world,mode", [(0, 2, 2, ""), (1, 2, 2, ""), (1, 2, 3, ""), (0, 3, 2, ""), (1, 3, 2, ""),
                                                  (1, 2, 2, "cells"), (1, 2, 3, "cells")])
 def test_separate_processes_step_one_system_together(nb, oracle, tmp_path, alg, dims, world, mode):

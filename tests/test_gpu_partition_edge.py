@@ -234,6 +234,84 @@ def test_cell_exchange_reproduces_the_single_gpu_run(nb, oracle, scenario, n, wo
             assert np.linalg.norm(o["vel"][own] - ref["vel"][own], axis=1).max() <= 0.1  # speeds are 1e4..1e5 m/s
 
 
+def step_ranks_following_the_box(nb, hip, ranks, n, levels):
+    """One step of handles that share one GPU by the protocol of nb_cells_level: the cell exchange
+    while the library says it applies, the position exchange while it is suspended."""
+    said = [s.cells_level() for s in ranks]
+    assert all(x == said[0] for x in said), said
+    level, gather = said[0]
+    levels.append(level)
+    if gather:
+        gather_between_ranks(hip, ranks, n, "pos")
+    if level < 0:
+        step_ranks_together(hip, ranks, n)
+        return
+    for part, op in ((0, np.maximum), (1, np.add)):
+        for s in ranks:
+            s.step_cells(part)
+        reduce_between_ranks(hip, ranks, part, op)
+    for s in ranks:
+        s.step_cells(2)
+
+
+def test_cell_exchange_is_suspended_when_the_box_outgrows_it(nb, oracle):
+    """A body leaving the system at speed makes the bounding box grow until the tree closes below the
+    last level the cell records can be exchanged at: the library then has the ranks gather their
+    positions once and exchange positions from there on.  The run must stay on the single-GPU run's
+    path across the switch."""
+    n, world, steps = 3001, 3, 200
+    b = nb.init_scenario(nb.SPIRAL, n, 21)
+    p = nb.default_params()
+    extent = np.abs(b["pos"]).max()
+    k = int(np.argmax(np.abs(b["pos"][:, 0])))
+    b["vel"][k] = (np.sign(b["pos"][k, 0]) * 0.04 * extent / p.dt, 0.0)  # 2 % of the box width per step
+    hip = _hip()
+    one = nb.NBodySim(n, nb.BARNES_HUT)
+    ranks = [nb.NBodySim(n, nb.BARNES_HUT) for _ in range(world)]
+    levels = []
+    try:
+        one.set_bodies(b)
+        for r, s in enumerate(ranks):
+            s.set_bodies(b)
+            s.set_partition(r, world)
+            s.set_exchange(nb.EXCHANGE_CELLS)
+        order = ranks[0].order()
+        for _ in range(steps):
+            one.update()
+            step_ranks_following_the_box(nb, hip, ranks, n, levels)
+        ref = one.read_bodies()
+        outs = [s.read_bodies() for s in ranks]
+    finally:
+        one.close()
+        for s in ranks:
+            s.close()
+    assert levels[0] >= 0 and levels[-1] == -1, levels[::16]
+    assert sorted(set(levels), key=levels.index)[:-1] == sorted(x for x in set(levels) if x >= 0)  # level only rises
+    chunk = (n + world - 1) // world
+    extent = np.abs(ref["pos"]).max()
+    for r, o in enumerate(outs):
+        own = order[min(n, r * chunk):min(n, (r + 1) * chunk)]
+        # after the switch every rank holds every position again.  200 steps of FP32 sums taken in
+        # another order: 3e-7 of the extent observed (1.4e-8 after 40 steps); positions that missed
+        # an exchange would be off by 1e-3 and more
+        assert np.linalg.norm(o["pos"] - ref["pos"], axis=1).max() <= 3e-6 * extent
+        assert np.linalg.norm(o["vel"][own] - ref["vel"][own], axis=1).max() <= 5.0  # speeds are 1e4..1e5 m/s
+
+
+def test_auto_exchange_prefers_positions_for_a_small_system(nb):
+    """NB_EXCHANGE_AUTO: 3000 positions are far less data than the records of 65 536 cells, so the
+    cell exchange starts suspended; nb_step_cells refuses, nb_step_local works."""
+    with nb.NBodySim(3000, nb.BARNES_HUT) as sim:
+        sim.setup(nb.SPIRAL, 2)
+        sim.set_partition(0, 2)
+        sim.set_exchange(nb.EXCHANGE_AUTO)
+        assert sim.cells_level() == (-1, False)
+        with pytest.raises(nb.NBodyError, match="suspended"):
+            sim.step_cells(0)
+        sim.step_local()
+        sim.step_finish()
+
+
 def test_cell_exchange_call_order(nb):
     with nb.NBodySim(100, nb.BARNES_HUT) as sim:
         sim.setup(nb.SPIRAL, 1)
