@@ -191,7 +191,7 @@ int nb_step_distributed(nb_sim *sim, int nsteps);
  * bodies, so nb_read_bodies all-gathers the positions first when the library holds the communicator
  * (a collective call then) and returns only this rank's velocities up to date.  Needs a tree that
  * closes at level <= 10, Euler integration and bucket_depth 0; switch it on after nb_set_partition /
- * nb_comm_init and before the first step.
+ * nb_comm_init and before the first step (nb_set_bodies goes back to NB_EXCHANGE_POSITIONS).
  * The level follows the bounding box: every 16 steps the host waits for the stream once and looks at
  * the box of the last step (the same on every rank).  A box that has grown so far that the tree
  * closes below level 10 SUSPENDS the cell exchange -- the ranks all-gather their positions once and

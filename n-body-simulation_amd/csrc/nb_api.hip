@@ -1,11 +1,13 @@
-// nb_api.hip -- the C ABI of libnbody_hip.so (declared in include/nbody.h).
+// nb_api.hip -- the C ABI of libnbody_hip.so (declared in include/nbody.h), two-dimensional bodies.
 //
 // nb_sim plays the role of the reference's BarnesHutCuda object
 // (src/gpu/BH/barnesHutCuda.cuh:49-80): it owns the device arrays, takes the initial
 // state once (setup) and advances it with update()-like steps, copying bodies back only
 // when asked.  State on the device is SoA: positions and velocities in FP64 (the
 // reference's precision, so integration adds no rounding of its own), and per step a
-// float4 record per body for the FP32 force kernels.
+// float4 record per body for the FP32 force kernels.  The entry points the 3-D handle has too
+// are written once, in nb_handle.h; this file holds the 2-D handle's own parts: the launches of
+// nb_direct.hip and nb_bh.hip, the cell exchange between GPUs, diagnostics and introspection.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -26,43 +28,23 @@ int fail(int status, const std::string &msg)
     return status;
 }
 
-}  // namespace nb
-
-using namespace nb;
-
-namespace nb {
-
-IntegrateArgs integrate_args(const nb_sim *s, int do_integrate)
-{
-    IntegrateArgs ia;
-    ia.acc_factor = s->units.acc_factor;
-    ia.dt = s->p.dt;
-    ia.dt_kick = (s->p.integrator == NB_INT_LEAPFROG && s->first_kick) ? 0.5 * s->p.dt : s->p.dt;
-    ia.inv_len_unit = 1.0 / s->units.len_unit;
-    for (int d = 0; d < 3; ++d)
-        ia.origin[d] = s->units.origin[d];
-    ia.do_integrate = do_integrate;
-    ia.static_fixed = (s->alg == NB_ALG_BARNES_HUT && s->p.bucket_depth > 0) ? 1 : 0;
-    return ia;
-}
-
 BhStepArgs bh_args(nb_sim *s, int do_integrate)
 {
     BhStepArgs a;
-    a.pos = s->pos;
+    a.pos = s->pos2d();
     a.mass = s->mass;
     a.radius = s->radius;
     a.mass_radius = s->mass_radius;
     a.dyn = s->dyn;
-    a.vel = s->vel;
-    a.acc = s->acc;
-    a.pos_out = s->pos;
+    a.vel = s->vel2d();
+    a.acc = s->acc2d();
+    a.pos_out = s->pos2d();
     a.n = s->n;
     a.t0 = s->t0;
     a.t1 = s->t1;
     a.units = s->units;
     a.fc = s->fc;
-    a.ia = integrate_args(s, do_integrate);
+    a.ia = make_integrate_args(s, do_integrate);
     a.theta = s->p.theta;
     a.bbox_margin = s->p.bbox_margin;
     a.collision_th = s->p.collision_th;
@@ -73,405 +55,141 @@ BhStepArgs bh_args(nb_sim *s, int do_integrate)
 
 }  // namespace nb
 
-namespace {
+using namespace nb;
 
-double pow2_floor_exp(double v) { return v > 0 ? std::floor(std::log2(v)) : 0.0; }
+// ---- what the shared entry points call (nb_handle.h) ----
 
-// The origin of the internal coordinates (the middle of the bodies' bounding box) and the powers
-// of two that bring the largest coordinate from there to [4, 8) and the largest mass to about 2^20.
-void choose_units(nb_sim *s, const nb_body *b, int n)
+int nb_sim::check_params(const nb_params &p)
 {
-    double lo[2] = {b[0].position.x, b[0].position.y}, hi[2] = {lo[0], lo[1]};
-    for (int i = 1; i < n; ++i) {
-        lo[0] = std::min(lo[0], b[i].position.x);
-        hi[0] = std::max(hi[0], b[i].position.x);
-        lo[1] = std::min(lo[1], b[i].position.y);
-        hi[1] = std::max(hi[1], b[i].position.y);
-    }
-    s->units.origin[0] = 0.5 * (lo[0] + hi[0]);
-    s->units.origin[1] = 0.5 * (lo[1] + hi[1]);
-    s->units.origin[2] = 0.0;
-    double maxc = 1.0, maxm = 1.0;
-    for (int i = 0; i < n; ++i) {
-        maxc = std::max(maxc, std::max(std::fabs(b[i].position.x - s->units.origin[0]),
-                                       std::fabs(b[i].position.y - s->units.origin[1])));
-        maxm = std::max(maxm, std::fabs(b[i].mass));
-    }
-    s->units.len_unit = std::ldexp(1.0, (int)pow2_floor_exp(maxc) - 2);
-    s->units.mass_unit = std::ldexp(1.0, (int)pow2_floor_exp(maxm) - 20);
-    s->units.acc_factor = s->p.gravity * s->units.mass_unit / (s->units.len_unit * s->units.len_unit);
-    const double lu = s->units.len_unit;
-    s->fc.eps2 = (float)(s->p.eps * s->p.eps / (lu * lu));
-    s->fc.eps3 = (float)(s->p.eps * s->p.eps / (lu * lu * lu));
-    s->fc.cth = (float)(s->p.collision_th / lu);
-    // Every evaluated pair is farther apart than collision_th, so r^3 >= cth^3: eps3 below
-    // 2^-26 of that cannot change a float sum r^3 + eps3.
-    const double c3 = (double)s->fc.cth * s->fc.cth * s->fc.cth;
-    s->fc.exact_denom = !((double)s->fc.eps3 <= std::ldexp(c3, -26));
-    s->fc.eps2_negligible = (double)s->fc.eps2 <= std::ldexp((double)s->fc.cth * s->fc.cth, -26);
-    // coordinates lie in [-8, 8): their float rounding is up to 2.4e-7 units, i.e. a relative 5e-6 of a
-    // distance of 0.05 units (the reference's cutoff in its own scenarios is 0.145 units)
-    s->fc.precise_near = s->fc.cth < 0.05f;
-}
-
-// Exchange order = bodies sorted by a 2 x 16-bit Morton code of their initial positions.
-// Index ranges of it are compact patches of space, which keeps the 64 bodies a wave walks the
-// tree for close together when the range is cut across GPUs, and gives the direct-sum tiles
-// small bounding boxes.  Only locality matters here, not the reference's cell boundaries.
-void exchange_order(const nb_body *b, int n, std::vector<uint32_t> &order)
-{
-    order.resize(n);
-    double mnx = b[0].position.x, mxx = mnx, mny = b[0].position.y, mxy = mny;
-    for (int i = 1; i < n; ++i) {
-        mnx = std::min(mnx, b[i].position.x);
-        mxx = std::max(mxx, b[i].position.x);
-        mny = std::min(mny, b[i].position.y);
-        mxy = std::max(mxy, b[i].position.y);
-    }
-    const double sx = mxx > mnx ? 65535.0 / (mxx - mnx) : 0.0, sy = mxy > mny ? 65535.0 / (mxy - mny) : 0.0;
-    auto spread = [](uint32_t v) {
-        v = (v | (v << 8)) & 0x00FF00FFu;
-        v = (v | (v << 4)) & 0x0F0F0F0Fu;
-        v = (v | (v << 2)) & 0x33333333u;
-        v = (v | (v << 1)) & 0x55555555u;
-        return v;
-    };
-    std::vector<uint64_t> kv(n);
-    for (int i = 0; i < n; ++i) {
-        const uint32_t qx = (uint32_t)((b[i].position.x - mnx) * sx), qy = (uint32_t)((b[i].position.y - mny) * sy);
-        kv[i] = ((uint64_t)(spread(qx) | (spread(qy) << 1)) << 32) | (uint32_t)i;
-    }
-    std::sort(kv.begin(), kv.end());
-    for (int i = 0; i < n; ++i)
-        order[i] = (uint32_t)(kv[i] & 0xffffffffu);
-}
-
-void mark(nb_sim *s, int k) { s->timer.mark(s->stream, k); }
-
-// Direct sum: its run-against-wave box tests rely on slot ranges being compact patches of space;
-// bodies wander, so the order is renewed now and then.  Steps between two renewals: they cost a
-// few passes over the per-body arrays, well below 1 % of the steps between at this interval.
-long refresh_interval(int n)
-{
-    const long interval = 50000000L / (n > 0 ? n : 1);
-    return interval < 64 ? 64 : (interval > 4096 ? 4096 : interval);
-}
-
-int step_local(nb_sim *s, int do_integrate)
-{
-    if (s->alg == NB_ALG_DIRECT) {
-        mark(s, 5);
-        NB_TRY(direct_step(s->stream, s->posm[s->cur], s->posm[s->cur ^ 1], s->rad_s, s->n, s->t0, s->t1 - s->t0, s->fc,
-                           integrate_args(s, do_integrate), s->dyn, s->pos, s->pos2, s->radius, s->p.collision_th,
-                           s->vel, s->acc, s->part, s->jsplit, s->ds_meta));
-        mark(s, 6);
-        return NB_OK;
-    }
-    BhStepArgs a = bh_args(s, do_integrate);
-    mark(s, 0);
-    NB_TRY(bh_bbox(s->stream, s->bh, a));
-    mark(s, 1);
-    NB_TRY(bh_keys(s->stream, s->bh, a));
-    mark(s, 2);
-    NB_TRY(bh_sort(s->stream, s->bh, a));
-    mark(s, 3);
-    NB_TRY(bh_build(s->stream, s->bh, a));
-    mark(s, 4);
-    NB_TRY(bh_com(s->stream, s->bh, a));
-    mark(s, 5);
-    NB_TRY(bh_force(s->stream, s->bh, a));
-    mark(s, 6);
+    if (p.bucket_depth < 0 || p.bucket_depth > 31)
+        return fail(NB_ERR_ARG, "nb_create: bucket_depth must be 0..31");
     return NB_OK;
 }
 
-int step_finish(nb_sim *s)
+int nb_sim::alloc_pipelines()
 {
-    s->first_kick = false;
-    s->stepped = true;
-    if (s->exchange != NB_EXCHANGE_POSITIONS)
-        s->cells_steps += 1;  // (the cell exchange is suspended: its level is still looked at every 16 steps)
-    if (s->alg == NB_ALG_DIRECT) {
-        // records of the bodies other ranks advanced come from the gathered positions
-        if (s->world > 1) {
-            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, s->n, 0, s->t0, s->units, s->p.collision_th,
-                             s->posm[s->cur ^ 1], s->rad_s));
-            NB_TRY(pack_posm(s->stream, s->pos2, s->mass, s->radius, s->n, s->t1, s->n, s->units, s->p.collision_th,
-                             s->posm[s->cur ^ 1], s->rad_s));
+    if (alg == NB_ALG_DIRECT) {
+        for (int k = 0; k < 2; ++k) {
+            NB_TRY(dev_alloc(posm[k], direct_record_floats4(n)));
+            NB_HIP(hipMemset(posm[k], 0, sizeof(float4) * direct_record_floats4(n)));
         }
-        s->cur ^= 1;
-        std::swap(s->pos, s->pos2);
+        NB_TRY(dev_alloc(rad_s, cap));
+        jsplit = direct_choose_jsplit(n, n);
+        part_cap = (size_t)jsplit * n;
+        NB_TRY(dev_alloc(part, part_cap));
+        NB_TRY(dev_alloc(ds_meta, direct_meta_bytes(n)));
+    } else {
+        NB_TRY(dev_alloc(mass_radius, cap));
+        NB_TRY(bh_alloc(bh, n));
     }
+    return static_scratch_init(device);
+}
+
+void nb_sim::free_pipelines()
+{
+    (void)hipFree(mass_radius);
+    (void)hipFree(posm[0]);
+    (void)hipFree(posm[1]);
+    (void)hipFree(rad_s);
+    (void)hipFree(part);
+    (void)hipFree(ds_meta);
+    bh_free(bh);
+}
+
+int nb_sim::direct_step(int do_integrate)
+{
+    timer.mark(stream, 5);
+    NB_TRY(nb::direct_step(stream, posm[cur], posm[cur ^ 1], rad_s, n, t0, t1 - t0, fc, make_integrate_args(this, do_integrate),
+                           dyn, pos2d(), pos2d_next(), radius, p.collision_th, vel2d(), acc2d(), part, jsplit, ds_meta));
+    timer.mark(stream, 6);
     return NB_OK;
 }
 
-int collect_timing(nb_sim *s) { return s->timer.step_done(s->stream); }
-
-void release(nb_sim *s)
+int nb_sim::bh_step(int do_integrate)
 {
-    (void)hipFree(s->pos);
-    (void)hipFree(s->pos2);
-    (void)hipFree(s->vel);
-    (void)hipFree(s->acc);
-    (void)hipFree(s->mass);
-    (void)hipFree(s->radius);
-    (void)hipFree(s->mass_radius);
-    (void)hipFree(s->dyn);
-    (void)hipFree(s->order_d);
-    (void)hipFree(s->posm[0]);
-    (void)hipFree(s->posm[1]);
-    (void)hipFree(s->rad_s);
-    (void)hipFree(s->part);
-    (void)hipFree(s->ds_meta);
-    bh_free(s->bh);
-    refresh_free(s->rb);
-    comm_destroy(s->comm);
-    s->comm = nullptr;
-    s->timer.destroy();
-    if (s->own_stream && s->stream)
-        (void)hipStreamDestroy(s->stream);
+    BhStepArgs a = bh_args(this, do_integrate);
+    timer.mark(stream, 0);
+    NB_TRY(bh_bbox(stream, bh, a));
+    timer.mark(stream, 1);
+    NB_TRY(bh_keys(stream, bh, a));
+    timer.mark(stream, 2);
+    NB_TRY(bh_sort(stream, bh, a));
+    timer.mark(stream, 3);
+    NB_TRY(bh_build(stream, bh, a));
+    timer.mark(stream, 4);
+    NB_TRY(bh_com(stream, bh, a));
+    timer.mark(stream, 5);
+    NB_TRY(bh_force(stream, bh, a));
+    timer.mark(stream, 6);
+    return NB_OK;
 }
 
-}  // namespace
+int nb_sim::direct_pack_all()
+{
+    cur = 0;
+    NB_TRY(pack_posm(stream, pos2d(), mass, radius, n, 0, n, units, p.collision_th, posm[0], rad_s));
+    NB_TRY(pad_posm(stream, posm[0], n));
+    // mass and cutoff radius never change: give the second buffer the same records
+    NB_HIP(hipMemcpyAsync(posm[1], posm[0], sizeof(float4) * direct_record_floats4(n), hipMemcpyDeviceToDevice, stream));
+    return NB_OK;
+}
+
+int nb_sim::direct_pack_others()
+{
+    NB_TRY(pack_posm(stream, pos2d_next(), mass, radius, n, 0, t0, units, p.collision_th, posm[cur ^ 1], rad_s));
+    return pack_posm(stream, pos2d_next(), mass, radius, n, t1, n, units, p.collision_th, posm[cur ^ 1], rad_s);
+}
+
+int nb_sim::direct_set_split(int nt)
+{
+    const int js = direct_choose_jsplit(n, nt);
+    const size_t need = (size_t)js * (size_t)nt;
+    if (need > part_cap) {
+        (void)hipFree(part);
+        part = nullptr;
+        part_cap = 0;
+        NB_TRY(dev_alloc(part, need));
+        part_cap = need;
+    }
+    jsplit = js;
+    return NB_OK;
+}
+
+int nb_sim::upload_extra(const double *mass_h, const double *radius_h)
+{
+    if (alg != NB_ALG_BARNES_HUT)
+        return NB_OK;
+    std::vector<double2> mr(n);
+    for (int k = 0; k < n; ++k)
+        mr[k] = make_double2(mass_h[k], radius_h[k]);
+    NB_HIP(hipMemcpy(mass_radius, mr.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+    return NB_OK;
+}
+
+int nb_sim::gather_extra() { return refresh_gather(stream, rb, mass_radius, sizeof(double2), n); }
+
+// The key depth the first steps will find, so that their launches are sized right from the start.
+int nb_sim::after_load() { return alg == NB_ALG_BARNES_HUT ? bh_prime(stream, bh, bh_args(this, 0)) : (int)NB_OK; }
 
 extern "C" {
 
 const char *nb_last_error(void) { return g_error.c_str(); }
 
-const char *nb_version(void) { return "nbody_hip 0.1 (gfx950)"; }
+const char *nb_version(void) { return "nbody_hip 0.2 (gfx950)"; }
 
-int nb_create(const nb_params *params, int n, int alg, nb_sim **out)
-{
-    if (!out)
-        return fail(NB_ERR_ARG, "nb_create: out is NULL");
-    *out = nullptr;
-    if (n < 1)
-        return fail(NB_ERR_ARG, "ERROR: need to have at least 1 body");
-    if (alg != NB_ALG_DIRECT && alg != NB_ALG_BARNES_HUT)
-        return fail(NB_ERR_ARG, "nb_create: alg must be 0 (direct sum) or 1 (Barnes-Hut)");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-        return fail(NB_ERR_HIP, "nb_create: no HIP device is visible; this library has no CPU path");
-    nb_sim *s = new nb_sim();
-    if (params)
-        s->p = *params;
-    else
-        nb_default_params(&s->p);
-    if (!(s->p.theta >= 0) || !(s->p.collision_th >= 0) || !(s->p.eps >= 0)) {
-        delete s;
-        return fail(NB_ERR_ARG, "nb_create: theta, collision_th and eps must be >= 0");
-    }
-    if (s->p.bucket_depth < 0 || s->p.bucket_depth > 31) {
-        delete s;
-        return fail(NB_ERR_ARG, "nb_create: bucket_depth must be 0..31");
-    }
-    if (s->p.integrator != NB_INT_EULER && s->p.integrator != NB_INT_LEAPFROG) {
-        delete s;
-        return fail(NB_ERR_ARG, "nb_create: integrator must be NB_INT_EULER or NB_INT_LEAPFROG");
-    }
-    s->n = n;
-    s->alg = alg;
-    s->t0 = 0;
-    s->t1 = n;
-    s->chunk = (size_t)n;
-    s->cap = (size_t)n + 64;
-    int rc = NB_OK;
-    auto chk = [&](int r) {
-        if (rc == NB_OK)
-            rc = r;
-    };
-    if (hipGetDevice(&s->device) != hipSuccess)
-        chk(fail(NB_ERR_HIP, "hipGetDevice failed"));
-    if (rc == NB_OK && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
-        chk(fail(NB_ERR_HIP, "hipStreamCreate failed"));
-    s->own_stream = rc == NB_OK;
-    chk(dev_alloc(s->pos, s->cap));
-    chk(dev_alloc(s->vel, s->cap));
-    chk(dev_alloc(s->acc, s->cap));
-    chk(dev_alloc(s->mass, s->cap));
-    chk(dev_alloc(s->radius, s->cap));
-    chk(dev_alloc(s->dyn, s->cap));
-    chk(dev_alloc(s->order_d, s->cap));
-    if (alg == NB_ALG_DIRECT) {
-        chk(dev_alloc(s->pos2, s->cap));
-        for (int k = 0; k < 2; ++k) {
-            chk(dev_alloc(s->posm[k], direct_record_floats4(n)));
-            if (rc == NB_OK && hipMemset(s->posm[k], 0, sizeof(float4) * direct_record_floats4(n)) != hipSuccess)
-                chk(fail(NB_ERR_HIP, "hipMemset failed"));
-        }
-        chk(dev_alloc(s->rad_s, s->cap));
-        s->jsplit = direct_choose_jsplit(n, n);
-        s->part_cap = (size_t)s->jsplit * n;
-        chk(dev_alloc(s->part, s->part_cap));
-        chk(dev_alloc(s->ds_meta, direct_meta_bytes(n)));
-        chk(refresh_alloc(s->rb, n));  // nb_step renews the order by itself for the direct sum
-    } else {
-        chk(dev_alloc(s->mass_radius, s->cap));
-        chk(bh_alloc(s->bh, n));
-    }
-    if (rc == NB_OK)
-        chk(s->timer.create());
-    if (rc == NB_OK)
-        chk(static_scratch_init(s->device));
-    if (rc != NB_OK) {
-        release(s);
-        delete s;
-        return rc;
-    }
-    *out = s;
-    return NB_OK;
-}
+int nb_create(const nb_params *params, int n, int alg, nb_sim **out) { return api_create(params, n, alg, out); }
 
-int nb_destroy(nb_sim *s)
-{
-    if (!s)
-        return NB_OK;
-    (void)hipStreamSynchronize(s->stream);
-    release(s);
-    delete s;
-    return NB_OK;
-}
+int nb_destroy(nb_sim *s) { return api_destroy(s); }
 
-int nb_set_stream(nb_sim *s, void *hip_stream)
-{
-    if (!s)
-        return fail(NB_ERR_ARG, "nb_set_stream: sim is NULL");
-    NB_HIP(hipStreamSynchronize(s->stream));
-    if (s->own_stream && s->stream)
-        (void)hipStreamDestroy(s->stream);
-    s->stream = (hipStream_t)hip_stream;
-    s->own_stream = false;
-    return NB_OK;
-}
-
-// Units, exchange order and device arrays from bodies given in the caller's order.
-static int load_bodies(nb_sim *s, const nb_body *b, int n)
-{
-    choose_units(s, b, n);
-    exchange_order(b, n, s->order);
-    std::vector<double2> pos(n), vel(n), acc(n);
-    std::vector<double> mass(n), radius(n);
-    std::vector<uint8_t> dyn(n);
-    for (int k = 0; k < n; ++k) {
-        const nb_body &x = b[s->order[k]];
-        pos[k] = make_double2(x.position.x, x.position.y);
-        vel[k] = make_double2(x.velocity.x, x.velocity.y);
-        acc[k] = make_double2(x.acceleration.x, x.acceleration.y);
-        mass[k] = x.mass;
-        radius[k] = x.radius;
-        dyn[k] = x.is_dynamic ? 1 : 0;
-    }
-    NB_HIP(hipStreamSynchronize(s->stream));
-    NB_HIP(hipMemcpy(s->pos, pos.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
-    NB_HIP(hipMemcpy(s->vel, vel.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
-    NB_HIP(hipMemcpy(s->acc, acc.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
-    NB_HIP(hipMemcpy(s->mass, mass.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-    NB_HIP(hipMemcpy(s->radius, radius.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-    NB_HIP(hipMemcpy(s->dyn, dyn.data(), n, hipMemcpyHostToDevice));
-    NB_HIP(hipMemcpy(s->order_d, s->order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
-    s->order_stale = false;
-    if (s->alg == NB_ALG_BARNES_HUT) {
-        std::vector<double2> mr(n);
-        for (int k = 0; k < n; ++k)
-            mr[k] = make_double2(mass[k], radius[k]);
-        NB_HIP(hipMemcpy(s->mass_radius, mr.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
-    }
-    if (s->alg == NB_ALG_DIRECT) {
-        s->cur = 0;
-        NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, n, 0, n, s->units, s->p.collision_th, s->posm[0], s->rad_s));
-        NB_TRY(pad_posm(s->stream, s->posm[0], n));
-        // mass and cutoff radius never change: give the second buffer the same records
-        NB_HIP(hipMemcpyAsync(s->posm[1], s->posm[0], sizeof(float4) * direct_record_floats4(n),
-                              hipMemcpyDeviceToDevice, s->stream));
-    }
-    NB_HIP(hipStreamSynchronize(s->stream));
-    if (s->alg == NB_ALG_BARNES_HUT)
-        NB_TRY(bh_prime(s->stream, s->bh, bh_args(s, 0)));
-    s->steps_in_order = 0;
-    return NB_OK;
-}
+int nb_set_stream(nb_sim *s, void *hip_stream) { return api_set_stream(s, hip_stream); }
 
 int nb_set_bodies(nb_sim *s, const nb_body *b, int n)
 {
-    if (!s || !b)
-        return fail(NB_ERR_ARG, "nb_set_bodies: NULL argument");
-    if (n != s->n)
-        return fail(NB_ERR_ARG, "nb_set_bodies: n differs from the n given to nb_create");
-    for (int i = 0; i < n; ++i)
-        if (!std::isfinite(b[i].position.x) || !std::isfinite(b[i].position.y) || !std::isfinite(b[i].mass))
-            return fail(NB_ERR_ARG, "nb_set_bodies: body " + std::to_string(i) + " is not finite");
-    NB_TRY(load_bodies(s, b, n));
-    s->have_bodies = true;
-    s->mid_step = false;
-    s->first_kick = true;
-    s->stepped = false;
-    return NB_OK;
-}
-
-// The slot -> caller index map on the host (fetched again after the device renewed it).
-static int host_order(nb_sim *s)
-{
-    if (!s->order_stale)
-        return NB_OK;
-    NB_HIP(hipStreamSynchronize(s->stream));
-    NB_HIP(hipMemcpy(s->order.data(), s->order_d, sizeof(uint32_t) * s->n, hipMemcpyDeviceToHost));
-    s->order_stale = false;
-    return NB_OK;
-}
-
-// Renews the exchange order on the device, everything enqueued on the stream (nb_refresh.h): new
-// order from the current positions, every per-body array gathered into it, the direct sum's
-// records packed again.  The float records' origin moves to the middle of the box the PREVIOUS
-// renewal saw (the device leaves it in host-visible memory; the host never waits for it), so a
-// drifting system keeps its precision.
-static int device_refresh(nb_sim *s)
-{
-    if (s->rb.n != s->n)
-        NB_TRY(refresh_alloc(s->rb, s->n));
-    if (s->rb.origin_set && s->alg == NB_ALG_DIRECT) {
-        s->units.origin[0] = ((volatile double *)s->rb.origin_host)[0];
-        s->units.origin[1] = ((volatile double *)s->rb.origin_host)[1];
-    }
-    NB_TRY(refresh_sort(s->stream, s->rb, (const double *)s->pos, 2, s->n));
-    NB_TRY(refresh_gather(s->stream, s->rb, s->pos, sizeof(double2), s->n));
-    NB_TRY(refresh_gather(s->stream, s->rb, s->vel, sizeof(double2), s->n));
-    NB_TRY(refresh_gather(s->stream, s->rb, s->acc, sizeof(double2), s->n));
-    NB_TRY(refresh_gather(s->stream, s->rb, s->mass, sizeof(double), s->n));
-    NB_TRY(refresh_gather(s->stream, s->rb, s->radius, sizeof(double), s->n));
-    NB_TRY(refresh_gather(s->stream, s->rb, s->mass_radius, sizeof(double2), s->n));
-    NB_TRY(refresh_gather(s->stream, s->rb, s->dyn, 1, s->n));
-    NB_TRY(refresh_gather(s->stream, s->rb, s->order_d, sizeof(uint32_t), s->n));
-    s->order_stale = true;
-    if (s->alg == NB_ALG_DIRECT) {
-        s->cur = 0;
-        NB_TRY(pack_posm(s->stream, s->pos, s->mass, s->radius, s->n, 0, s->n, s->units, s->p.collision_th, s->posm[0],
-                         s->rad_s));
-        NB_TRY(pad_posm(s->stream, s->posm[0], s->n));
-        NB_HIP(hipMemcpyAsync(s->posm[1], s->posm[0], sizeof(float4) * direct_record_floats4(s->n), hipMemcpyDeviceToDevice,
-                              s->stream));
-    }
-    s->steps_in_order = 0;
-    return NB_OK;
-}
-
-int nb_refresh_order(nb_sim *s)
-{
-    if (!s)
-        return fail(NB_ERR_ARG, "nb_refresh_order: sim is NULL");
-    if (!s->have_bodies)
-        return fail(NB_ERR_STATE, "nb_refresh_order: no bodies were set");
-    if (s->mid_step)
-        return fail(NB_ERR_STATE, "nb_refresh_order: a split step is in flight");
-    // (a partitioned simulation: the caller has all-gathered the velocity buffer, see nbody.h)
-    return device_refresh(s);
-}
-
-int nb_velocity_buffer(nb_sim *s, void **device_ptr, size_t *chunk_records, size_t *record_bytes)
-{
-    if (!s || !device_ptr || !chunk_records || !record_bytes)
-        return fail(NB_ERR_ARG, "nb_velocity_buffer: NULL argument");
-    *device_ptr = s->vel;
-    *chunk_records = s->chunk;
-    *record_bytes = sizeof(double2);
+    NB_TRY(api_set_bodies(s, b, n));
+    // the exchange mode belongs to a run: the new bodies start with the position exchange
+    s->exchange = NB_EXCHANGE_POSITIONS;
+    s->cells_active = false;
+    s->cells_phase = 0;
     return NB_OK;
 }
 
@@ -486,56 +204,36 @@ int nb_setup(nb_sim *s, int scenario, unsigned seed)
     return nb_set_bodies(s, b.data(), s->n);
 }
 
+int nb_refresh_order(nb_sim *s) { return api_refresh_order(s); }
+
+int nb_velocity_buffer(nb_sim *s, void **device_ptr, size_t *chunk_records, size_t *record_bytes)
+{
+    return api_buffer(s, "velocity_buffer", s ? s->vel : nullptr, device_ptr, chunk_records, record_bytes);
+}
+
+int nb_exchange_buffer(nb_sim *s, void **device_ptr, size_t *chunk_records, size_t *record_bytes)
+{
+    // direct sum writes the new positions to the other buffer; mid-step that is the one to gather
+    double *buf = !s ? nullptr : ((s->alg == NB_ALG_DIRECT && s->mid_step) ? s->pos2 : s->pos);
+    return api_buffer(s, "exchange_buffer", buf, device_ptr, chunk_records, record_bytes);
+}
+
 int nb_step_local(nb_sim *s)
 {
-    if (!s)
-        return fail(NB_ERR_ARG, "nb_step_local: sim is NULL");
-    if (!s->have_bodies)
-        return fail(NB_ERR_STATE, "nb_step_local: no bodies were set");
-    if (s->mid_step)
-        return fail(NB_ERR_STATE, "nb_step_local: the previous step was not finished");
-    if (s->cells_active)
+    if (s && s->cells_active)
         return fail(NB_ERR_STATE, "nb_step_local: with the cell exchange a step goes through nb_step_cells");
-    NB_TRY(step_local(s, 1));
-    s->mid_step = true;
-    return NB_OK;
+    return api_step_local(s);
 }
 
-int nb_step_finish(nb_sim *s)
-{
-    if (!s)
-        return fail(NB_ERR_ARG, "nb_step_finish: sim is NULL");
-    if (!s->mid_step)
-        return fail(NB_ERR_STATE, "nb_step_finish: nb_step_local was not called");
-    NB_TRY(step_finish(s));
-    s->mid_step = false;
-    return collect_timing(s);
-}
+int nb_step_finish(nb_sim *s) { return api_step_finish(s); }
 
-int nb_step(nb_sim *s, int nsteps)
-{
-    if (!s)
-        return fail(NB_ERR_ARG, "nb_step: sim is NULL");
-    if (nsteps < 0)
-        return fail(NB_ERR_ARG, "nb_step: nsteps < 0");
-    if (!s->have_bodies)
-        return fail(NB_ERR_STATE, "nb_step: no bodies were set");
-    if (s->world != 1)
-        return fail(NB_ERR_STATE, "nb_step: a partitioned simulation steps with nb_step_local / nb_step_finish");
-    if (s->mid_step)
-        return fail(NB_ERR_STATE, "nb_step: a split step is in flight");
-    const long interval = refresh_interval(s->n);
-    for (int k = 0; k < nsteps; ++k) {
-        NB_TRY(step_local(s, 1));
-        NB_TRY(step_finish(s));
-        NB_TRY(collect_timing(s));
-        if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= interval)
-            NB_TRY(device_refresh(s));
-    }
-    return NB_OK;
-}
+int nb_step(nb_sim *s, int nsteps) { return api_step(s, nsteps); }
+
+int nb_set_partition(nb_sim *s, int rank, int world) { return api_set_partition(s, rank, world); }
 
 // ---- cell exchange ----
+
+static void mark(nb_sim *s, int k) { s->timer.mark(s->stream, k); }
 
 // The rank's own bodies as a simulation of their own: arrays offset to slot t0, n = their number.
 static BhStepArgs cells_args(nb_sim *s, int do_integrate)
@@ -568,7 +266,7 @@ static int choose_cells_levels(nb_sim *s)
     const int l = closed_level_for(1.5 * w, 1.5 * h, s->p.theta, s->p.collision_th);
     if (l > cells_max_level())
         return -1;
-    if (s->exchange == NB_EXCHANGE_AUTO && 2 * cells_agg_doubles(l) * sizeof(double) > sizeof(double2) * (size_t)s->n)
+    if (s->exchange == NB_EXCHANGE_AUTO && 2 * cells_agg_doubles(l) * sizeof(double) > 2 * sizeof(double) * (size_t)s->n)
         return -1;
     return l;
 }
@@ -721,137 +419,52 @@ int nb_comm_unique_id(void *id, size_t bytes)
     return comm_unique_id(id);
 }
 
-int nb_comm_init(nb_sim *s, int rank, int world, const void *id)
-{
-    if (!s || !id)
-        return fail(NB_ERR_ARG, "nb_comm_init: NULL argument");
-    if (s->comm)
-        return fail(NB_ERR_STATE, "nb_comm_init: the simulation already has a communicator");
-    int device = -1;
-    NB_HIP(hipGetDevice(&device));
-    if (device != s->device)
-        return fail(NB_ERR_STATE, "nb_comm_init: the handle's device is not the current one");
-    NB_TRY(nb_set_partition(s, rank, world));
-    return comm_create(&s->comm, rank, world, id);
-}
+int nb_comm_init(nb_sim *s, int rank, int world, const void *id) { return api_comm_init(s, rank, world, id); }
 
 int nb_step_distributed(nb_sim *s, int nsteps)
 {
-    if (!s)
-        return fail(NB_ERR_ARG, "nb_step_distributed: sim is NULL");
-    if (nsteps < 0)
-        return fail(NB_ERR_ARG, "nb_step_distributed: nsteps < 0");
-    if (!s->comm)
-        return fail(NB_ERR_STATE, "nb_step_distributed: call nb_comm_init first");
-    if (!s->have_bodies)
-        return fail(NB_ERR_STATE, "nb_step_distributed: no bodies were set");
-    if (s->mid_step || s->cells_phase != 0)
+    NB_TRY(check_distributed(s, nsteps));
+    if (s->cells_phase != 0)
         return fail(NB_ERR_STATE, "nb_step_distributed: a split step is in flight");
     for (int k = 0; k < nsteps; ++k) {
         bool gather = false;
         NB_TRY(cells_housekeeping(s, &gather));
         if (gather)  // the cell exchange was suspended: from here on every rank holds all positions again
-            NB_TRY(comm_all_gather_f64(s->comm, (double *)s->pos, 2 * s->chunk, s->stream));
-        if (s->cells_active) {
-            // two reductions per step instead of the gather of all positions: the ranks' extents (4
-            // doubles, maximum) and the records of the cells of the keys' last level (sum)
-            NB_TRY(nb_step_cells(s, 0));
-            NB_TRY(comm_all_reduce_max_f64(s->comm, s->bh.red4, 4, s->stream));
-            NB_TRY(nb_step_cells(s, 1));
-            NB_TRY(comm_all_reduce_sum_f64(s->comm, s->bh.agg, cells_agg_doubles(s->cells_levels), s->stream));
-            NB_TRY(nb_step_cells(s, 2));
+            NB_TRY(comm_all_gather_f64(s->comm, s->pos, 2 * s->chunk, s->stream));
+        if (!s->cells_active) {
+            NB_TRY(distributed_position_step(s));
             continue;
         }
-        NB_TRY(step_local(s, 1));
-        // the new positions of every rank's slice, in place, ordered on the stream with the kernels
-        // before and after: the host does not wait
-        double2 *buf = s->alg == NB_ALG_DIRECT ? s->pos2 : s->pos;
-        NB_TRY(comm_all_gather_f64(s->comm, (double *)buf, 2 * s->chunk, s->stream));
-        mark(s, StageTimer::STAGE_END);
-        NB_TRY(step_finish(s));
-        NB_TRY(collect_timing(s));
-        if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= refresh_interval(s->n)) {
-            // every rank renews the order from the same positions; the new slices hold bodies other
-            // ranks advanced so far, whose velocities come with one more all-gather
-            NB_TRY(comm_all_gather_f64(s->comm, (double *)s->vel, 2 * s->chunk, s->stream));
-            NB_TRY(device_refresh(s));
-        }
+        // two reductions per step instead of the gather of all positions: the ranks' extents (4
+        // doubles, maximum) and the records of the cells of the keys' last level (sum)
+        NB_TRY(nb_step_cells(s, 0));
+        NB_TRY(comm_all_reduce_max_f64(s->comm, s->bh.red4, 4, s->stream));
+        NB_TRY(nb_step_cells(s, 1));
+        NB_TRY(comm_all_reduce_sum_f64(s->comm, s->bh.agg, cells_agg_doubles(s->cells_levels), s->stream));
+        NB_TRY(nb_step_cells(s, 2));
     }
     return NB_OK;
 }
 
 int nb_compute_accel(nb_sim *s)
 {
-    if (!s)
-        return fail(NB_ERR_ARG, "nb_compute_accel: sim is NULL");
-    if (!s->have_bodies)
-        return fail(NB_ERR_STATE, "nb_compute_accel: no bodies were set");
-    if (s->mid_step)
-        return fail(NB_ERR_STATE, "nb_compute_accel: a split step is in flight");
-    if (s->cells_active)
+    if (s && s->cells_active)
         return fail(NB_ERR_STATE, "nb_compute_accel: with the cell exchange this rank does not hold the other ranks' "
                                   "positions");
-    NB_TRY(step_local(s, 0));
-    return collect_timing(s);
+    return api_compute_accel(s);
 }
 
-int nb_sync(nb_sim *s)
-{
-    if (!s)
-        return fail(NB_ERR_ARG, "nb_sync: sim is NULL");
-    NB_HIP(hipStreamSynchronize(s->stream));
-    return NB_OK;
-}
+int nb_sync(nb_sim *s) { return api_sync(s); }
 
 int nb_read_bodies(nb_sim *s, nb_body *out)
 {
-    if (!s || !out)
-        return fail(NB_ERR_ARG, "nb_read_bodies: NULL argument");
-    if (!s->have_bodies)
-        return fail(NB_ERR_STATE, "nb_read_bodies: no bodies were set");
-    const int n = s->n;
-    std::vector<double2> pos(n), vel(n), acc(n);
-    std::vector<double> mass(n), radius(n);
-    std::vector<uint8_t> dyn(n);
-    // leapfrog keeps velocities half a step behind the positions; bring them level with the
-    // force at the current positions
-    if (s->cells_phase != 0)
-        return fail(NB_ERR_STATE, "nb_read_bodies: a split step is in flight");
-    if (s->cells_active && s->comm)  // the other ranks' positions (a collective call)
-        NB_TRY(comm_all_gather_f64(s->comm, (double *)s->pos, 2 * s->chunk, s->stream));
-    const bool half_step = s->p.integrator == NB_INT_LEAPFROG && !s->first_kick && !s->mid_step &&
-                           s->exchange == NB_EXCHANGE_POSITIONS;
-    if (half_step) {
-        // this force evaluation is not a step: keep it out of the per-stage timing
-        const int timing = s->timer.on;
-        s->timer.on = 0;
-        const int rc = step_local(s, 0);
-        s->timer.on = timing;
-        NB_TRY(rc);
+    if (s && out && s->have_bodies) {
+        if (s->cells_phase != 0)
+            return fail(NB_ERR_STATE, "nb_read_bodies: a split step is in flight");
+        if (s->cells_active && s->comm)  // the other ranks' positions (a collective call)
+            NB_TRY(comm_all_gather_f64(s->comm, s->pos, 2 * s->chunk, s->stream));
     }
-    NB_HIP(hipStreamSynchronize(s->stream));
-    NB_TRY(host_order(s));
-    NB_HIP(hipMemcpy(pos.data(), s->pos, sizeof(double2) * n, hipMemcpyDeviceToHost));
-    NB_HIP(hipMemcpy(vel.data(), s->vel, sizeof(double2) * n, hipMemcpyDeviceToHost));
-    NB_HIP(hipMemcpy(acc.data(), s->acc, sizeof(double2) * n, hipMemcpyDeviceToHost));
-    NB_HIP(hipMemcpy(mass.data(), s->mass, sizeof(double) * n, hipMemcpyDeviceToHost));
-    NB_HIP(hipMemcpy(radius.data(), s->radius, sizeof(double) * n, hipMemcpyDeviceToHost));
-    NB_HIP(hipMemcpy(dyn.data(), s->dyn, n, hipMemcpyDeviceToHost));
-    for (int k = 0; k < n; ++k) {
-        nb_body &x = out[s->order[k]];
-        std::memset(&x, 0, sizeof(x));
-        x.is_dynamic = dyn[k];
-        x.mass = mass[k];
-        x.radius = radius[k];
-        x.position = {pos[k].x, pos[k].y};
-        x.velocity = {vel[k].x, vel[k].y};
-        x.acceleration = {acc[k].x, acc[k].y};
-        if (half_step && k >= s->t0 && k < s->t1) {
-            x.velocity.x += 0.5 * s->p.dt * acc[k].x;
-            x.velocity.y += 0.5 * s->p.dt * acc[k].y;
-        }
-    }
-    return NB_OK;
+    return api_read_bodies(s, out);
 }
 
 int nb_diagnostics(nb_sim *s, double *out, int count)
@@ -880,7 +493,7 @@ int nb_diagnostics(nb_sim *s, double *out, int count)
     if (count > 7 && s->n <= 131072) {
         double *d = nullptr;
         NB_TRY(dev_alloc(d, 1));
-        int rc = potential_energy(s->stream, s->pos, s->mass, s->radius, s->n, s->p.gravity, s->p.eps,
+        int rc = potential_energy(s->stream, s->pos2d(), s->mass, s->radius, s->n, s->p.gravity, s->p.eps,
                                   s->p.collision_th, d);
         if (rc == NB_OK && hipStreamSynchronize(s->stream) == hipSuccess)
             (void)hipMemcpy(&v[7], d, sizeof(double), hipMemcpyDeviceToHost);
@@ -892,64 +505,9 @@ int nb_diagnostics(nb_sim *s, double *out, int count)
     return NB_OK;
 }
 
-int nb_set_partition(nb_sim *s, int rank, int world)
-{
-    if (!s)
-        return fail(NB_ERR_ARG, "nb_set_partition: sim is NULL");
-    if (world < 1 || world > 64 || rank < 0 || rank >= world)
-        return fail(NB_ERR_ARG, "nb_set_partition: need 0 <= rank < world <= 64");
-    if (!s->have_bodies)
-        return fail(NB_ERR_STATE, "nb_set_partition: set the bodies first");
-    if (s->mid_step)
-        return fail(NB_ERR_STATE, "nb_set_partition: a split step is in flight");
-    if (s->stepped)
-        return fail(NB_ERR_STATE, "nb_set_partition: the simulation was stepped already; set the bodies again first");
-    s->rank = rank;
-    s->world = world;
-    s->chunk = ((size_t)s->n + world - 1) / world;
-    s->t0 = (int)std::min((size_t)s->n, rank * s->chunk);
-    s->t1 = (int)std::min((size_t)s->n, (rank + 1) * s->chunk);
-    if (s->alg == NB_ALG_DIRECT) {
-        // fewer targets per rank: split the sources further so the chip stays full
-        const int js = direct_choose_jsplit(s->n, s->t1 - s->t0);
-        const size_t need = (size_t)js * (size_t)(s->t1 - s->t0);
-        if (need > s->part_cap) {
-            (void)hipFree(s->part);
-            s->part = nullptr;
-            s->part_cap = 0;
-            NB_TRY(dev_alloc(s->part, need));
-            s->part_cap = need;
-        }
-        s->jsplit = js;
-    }
-    return NB_OK;
-}
+int nb_set_stage_timing(nb_sim *s, int on) { return api_set_stage_timing(s, on); }
 
-int nb_exchange_buffer(nb_sim *s, void **device_ptr, size_t *chunk_records, size_t *record_bytes)
-{
-    if (!s || !device_ptr || !chunk_records || !record_bytes)
-        return fail(NB_ERR_ARG, "nb_exchange_buffer: NULL argument");
-    // direct sum writes the new positions to the other buffer; mid-step that is the one to gather
-    *device_ptr = (s->alg == NB_ALG_DIRECT && s->mid_step) ? s->pos2 : s->pos;
-    *chunk_records = s->chunk;
-    *record_bytes = sizeof(double2);
-    return NB_OK;
-}
-
-int nb_set_stage_timing(nb_sim *s, int on)
-{
-    if (!s)
-        return fail(NB_ERR_ARG, "nb_set_stage_timing: sim is NULL");
-    s->collect_stats = (on & 2) ? 1 : 0;
-    return s->timer.set(s->stream, on & 1);
-}
-
-int nb_stage_ms(nb_sim *s, float *out, int count)
-{
-    if (!s || !out)
-        return fail(NB_ERR_ARG, "nb_stage_ms: NULL argument");
-    return s->timer.read(s->stream, out, count);
-}
+int nb_stage_ms(nb_sim *s, float *out, int count) { return api_stage_ms(s, out, count); }
 
 int nb_debug_read(nb_sim *s, int which, void *out, size_t bytes, size_t *written)
 {

@@ -1,50 +1,45 @@
-// nb_sim.h -- the 2-D simulation handle behind the nb_ entry points (internal).
+// nb_sim.h -- the 2-D simulation handle behind the nb_ entry points (internal): the state every
+// handle has (nb_handle.h) plus the 2-D pipelines' buffers, the cell exchange between GPUs and the
+// hooks the shared entry points call (defined in nb_api.hip).
 #pragma once
 
-#include <vector>
-
 #include "nb_bh.h"
-#include "nb_comm.h"
-#include "nb_common.h"
-#include "nb_refresh.h"
-#include "nb_timing.h"
+#include "nb_handle.h"
 
-struct nb_sim {
-    nb_params p;
-    int n = 0;
-    int alg = 0;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    bool have_bodies = false;
-    bool first_kick = true;  // leapfrog: the next step is the first since the bodies were set
-    bool stepped = false;    // a step was taken since the bodies were set
-    long steps_in_order = 0; // steps since the exchange order was last derived from the positions
+struct nb_sim : nb::SimCore<2> {
+    static constexpr const char *PFX = "nb_";
+    using Body = nb_body;
+    static double coord(const nb_body &b, int d) { return d == 0 ? b.position.x : b.position.y; }
+    static double velocity(const nb_body &b, int d) { return d == 0 ? b.velocity.x : b.velocity.y; }
+    static double acceleration(const nb_body &b, int d) { return d == 0 ? b.acceleration.x : b.acceleration.y; }
+    static void store(nb_body &b, const double *p, const double *v, const double *a)
+    {
+        b.position = {p[0], p[1]};
+        b.velocity = {v[0], v[1]};
+        b.acceleration = {a[0], a[1]};
+    }
+    static int check_params(const nb_params &p);
 
-    nb::Units units{};
-    nb::ForceConsts fc{};
+    // the FP64 arrays as the 2-D kernels take them
+    double2 *pos2d() const { return (double2 *)pos; }
+    double2 *pos2d_next() const { return (double2 *)pos2; }
+    double2 *vel2d() const { return (double2 *)vel; }
+    double2 *acc2d() const { return (double2 *)acc; }
 
-    // state in exchange order; pos has room for world*chunk records
-    size_t cap = 0;
-    double2 *pos = nullptr, *vel = nullptr, *acc = nullptr;
-    double2 *pos2 = nullptr;  // direct sum: the other FP64 position buffer (pos is the current one)
-    double *mass = nullptr, *radius = nullptr;
     double2 *mass_radius = nullptr;  // Barnes-Hut: {mass, radius} per body (one gather instead of two)
-    uint8_t *dyn = nullptr;
+
+    // direct sum
     float4 *posm[2] = {nullptr, nullptr};
     float *rad_s = nullptr;
     int cur = 0;
-    std::vector<uint32_t> order;  // caller index of the body in each exchange-order slot
-    uint32_t *order_d = nullptr;  // the same on the device
-    bool order_stale = false;     // the device renewed the order; `order` is fetched when next needed
-    nb::RefreshBuffers rb;        // buffers of the renewal (made at nb_create for the direct sum, else on first use)
+    double2 *part = nullptr;  // part_cap records
+    int jsplit = 1;
+    uint8_t *ds_meta = nullptr;  // per-run bounding boxes (direct_meta_bytes)
 
-    // partition
-    int rank = 0, world = 1;
-    size_t chunk = 0;
-    int t0 = 0, t1 = 0;
-    bool mid_step = false;
-    nb::Comm *comm = nullptr;  // RCCL communicator of nb_comm_init (null: none)
+    // Barnes-Hut
+    nb::BhBuffers bh;
+
+    // what the ranks exchange
     int exchange = 0;          // nb_exchange: what the ranks exchange each step
     int cells_levels = -1;     // cell exchange: digits of the keys (the same on every rank)
     bool cells_active = false; // cell exchange: in use for the coming steps (else suspended: positions are exchanged)
@@ -52,23 +47,29 @@ struct nb_sim {
     long cells_checked = -1;   // cell exchange: the step count at which the level was last looked at
     int cells_phase = 0;       // cell exchange by hand: the next part of the step (0, 1, 2)
 
-    // direct sum
-    double2 *part = nullptr;
-    size_t part_cap = 0;  // records allocated in part
-    int jsplit = 1;
-    uint8_t *ds_meta = nullptr;  // per-run bounding boxes (direct_meta_bytes)
-
-    // Barnes-Hut
-    nb::BhBuffers bh;
-    int collect_stats = 0;
-
-    nb::StageTimer timer;
+    bool static_fixed() const { return alg == NB_ALG_BARNES_HUT && p.bucket_depth > 0; }
+    int alloc_pipelines();
+    void free_pipelines();
+    int direct_step(int do_integrate);
+    int bh_step(int do_integrate);
+    int direct_pack_all();
+    int direct_pack_others();
+    void direct_flip() { cur ^= 1; }
+    int direct_set_split(int nt);
+    int upload_extra(const double *mass_h, const double *radius_h);
+    int gather_extra();
+    int after_load();
+    void count_step()
+    {
+        if (exchange != NB_EXCHANGE_POSITIONS)
+            cells_steps += 1;  // (also while the cell exchange is suspended: its level is looked at every 16 steps)
+    }
 };
 
 namespace nb {
 
-// Arguments of a force evaluation (do_integrate = 0) or a step (1) of the handle's current state.
-IntegrateArgs integrate_args(const nb_sim *s, int do_integrate);
+// Arguments of the Barnes-Hut pipeline for a force evaluation (do_integrate = 0) or a step (1) of
+// the handle's current state.
 BhStepArgs bh_args(nb_sim *s, int do_integrate);
 
 // Looks up, once per device and with that device current, where the library's static scratch

@@ -91,7 +91,7 @@ extern "C" int nb_compute_accel_static(nb_sim *s, const double *pos_xy, double *
     NB_TRY(bh_carve(bh, n, ptr + 2 * rec_bytes, STATIC_SCRATCH_BYTES - 2 * rec_bytes, nullptr));
 
     const dim3 grid((n + 255) / 256);
-    hipLaunchKernelGGL(k_static_gather, grid, dim3(256), 0, stream, (const double2 *)pos_xy, s->order_d, s->acc, n, pos_x, acc_x);
+    hipLaunchKernelGGL(k_static_gather, grid, dim3(256), 0, stream, (const double2 *)pos_xy, s->order_d, s->acc2d(), n, pos_x, acc_x);
     NB_HIP(hipGetLastError());
     BhStepArgs a = bh_args(s, 0);
     a.pos = pos_x;
