@@ -255,10 +255,12 @@ int nb_stage_ms(nb_sim *sim, float *out, int count);
  * device state by it, on the device and asynchronously on the simulation's stream (a bounding box,
  * a radix sort of Morton codes, one gather per per-body array).  Nothing the caller sees changes
  * (nb_read_bodies keeps returning bodies in the caller's order; results differ only by the
- * rounding of a different summation order); it restores the speed of long direct-sum runs, whose
- * kernel relies on neighbouring slots being neighbours in space.  nb_step and nb_step_distributed
- * do it by themselves for the direct sum every max(64, min(4096, 5e7 / n)) steps.  The reference
- * keeps bodies in creation order and has nothing of the kind.
+ * rounding of a different summation order); it restores the speed of long runs: the direct-sum
+ * kernel relies on neighbouring slots being neighbours in space, and the Barnes-Hut pipeline gathers
+ * the state through its per-step sort, whose permutation drifts away from the identity as the bodies
+ * mix.  nb_step and nb_step_distributed do it by themselves, every max(64, min(4096, 5e7 / n)) steps
+ * for the direct sum and every 256 steps for Barnes-Hut (not while cells are exchanged: a rank then
+ * holds only its own bodies).  The reference keeps bodies in creation order and has nothing of the kind.
  * A partitioned simulation driven through nb_step_local / nb_step_finish may call it between
  * steps on EVERY rank, after all-gathering the velocity buffer the way the position buffer is
  * gathered (nb_velocity_buffer: same layout): every rank then derives the same order, and the

@@ -43,7 +43,7 @@ struct SimCore {
     bool have_bodies = false;
     bool first_kick = true;   // leapfrog: the next step is the first since the bodies were set
     bool stepped = false;     // a step was taken since the bodies were set
-    long steps_in_order = 0;  // direct sum: steps since the order was last derived from the positions
+    long steps_in_order = 0;  // steps since the exchange order was last derived from the positions
 
     Units units{};
     ForceConsts fc{};
@@ -189,11 +189,17 @@ IntegrateArgs make_integrate_args(const S *s, int do_integrate)
     return ia;
 }
 
-// Direct sum: its run-against-wave box tests rely on slot ranges being compact patches of space;
-// bodies wander, so the order is renewed now and then.  Steps between two renewals: they cost a
+// Steps between two renewals of the exchange order (device_refresh).  Direct sum: its run-against-wave
+// box tests rely on slot ranges being compact patches of space, and bodies wander; a renewal costs a
 // few passes over the per-body arrays, well below 1 % of the steps between at this interval.
-inline long refresh_interval(int n)
+// Barnes-Hut sorts every step anyway, but its leaf pass and the traversal's epilogue gather and
+// scatter the FP64 state through that sort's permutation, which drifts away from the identity as
+// the bodies mix (collision discs N = 5 M: 1.74 -> 1.65 ms/step at step 300, 2.21 -> 1.95 at step
+// 620 right after a renewal that takes 2.7 ms): every 256 steps.
+inline long refresh_interval(int n, int alg)
 {
+    if (alg != NB_ALG_DIRECT)
+        return 256;
     const long interval = 50000000L / (n > 0 ? n : 1);
     return interval < 64 ? 64 : (interval > 4096 ? 4096 : interval);
 }
@@ -540,12 +546,12 @@ int api_step(S *s, int nsteps)
                                       "step_finish");
     if (s->mid_step)
         return fail(NB_ERR_STATE, fn<S>("step: a split step is in flight"));
-    const long interval = refresh_interval(s->n);
+    const long interval = refresh_interval(s->n, s->alg);
     for (int k = 0; k < nsteps; ++k) {
         NB_TRY(step_local(s, 1));
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
-        if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= interval)
+        if (++s->steps_in_order >= interval)
             NB_TRY(device_refresh(s));
     }
     return NB_OK;
@@ -617,7 +623,7 @@ int distributed_position_step(S *s)
     s->timer.mark(s->stream, StageTimer::STAGE_END);
     NB_TRY(step_finish(s));
     NB_TRY(collect_timing(s));
-    if (s->alg == NB_ALG_DIRECT && ++s->steps_in_order >= refresh_interval(s->n)) {
+    if (++s->steps_in_order >= refresh_interval(s->n, s->alg)) {
         // every rank renews the order from the same positions; the new slices hold bodies other
         // ranks advanced so far, whose velocities come with one more all-gather
         NB_TRY(comm_all_gather_f64(s->comm, s->vel, S::D * s->chunk, s->stream));

@@ -24,6 +24,18 @@ common = Counter(s[2] for s in steps).most_common(1)[0][0]
 sel = [s for s in steps if s[2] == common]
 sel = sel[len(sel) // 4:]
 n = len(sel)
+if "--last" in sys.argv:
+    # per-kernel mean time over the last steps of the trace (whatever their kernel count)
+    k = int(sys.argv[sys.argv.index("--last") + 1])
+    per = {}
+    a0 = starts[-k - 1]
+    for s0, e0, name in rows[a0:starts[-1]]:
+        short = name.split("(")[0].replace("void ", "").replace("nb::", "")
+        c = per.setdefault(short, [0, 0])
+        c[0] += 1
+        c[1] += e0 - s0
+    for name, (cnt, tot) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        print("  %-34s %5.1f launches/step  %8.1f us/step" % (name[:34], cnt / k, tot / k / 1e3))
 print("steps with %d kernels: %d used; wall %.1f us, kernels %.1f us, idle between kernels %.1f us (%.1f us per launch)" % (
     common, n, sum(s[0] for s in sel) / n / 1e3, sum(s[1] for s in sel) / n / 1e3,
     sum(s[0] - s[1] for s in sel) / n / 1e3, sum(s[0] - s[1] for s in sel) / n / 1e3 / common))

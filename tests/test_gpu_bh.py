@@ -634,3 +634,31 @@ def test_leaf_sums_of_runs_that_cross_chunk_boundaries(nb, oracle):
     ref = oracle.bh_accel(b)
     dyn = b["is_dynamic"] != 0
     assert rel_err(acc[dyn], ref[dyn]).max() <= ACC_EXPECTED
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_long_tree_run_renews_its_order_by_itself(nb, oracle, dims):
+    """nb_step renews the exchange order every 256 steps for Barnes-Hut (the per-step sort's
+    permutation drifts away from the identity as bodies mix, and the leaf pass gathers through it).
+    300 steps through nb_step against 300 split steps, which never renew: the same run up to FP32
+    summation order, and the slot -> body map has changed on the way."""
+    n = 3000
+    if dims == 2:
+        b = oracle.scenario(0, n, 8)
+        make = lambda: nb.NBodySim(n, nb.BARNES_HUT)  # noqa: E731
+    else:
+        b = oracle.scenario3(0, n, 8, thickness=4.0e10)
+        make = lambda: nb.NBodySim3(n, nb.BARNES_HUT)  # noqa: E731
+    with make() as auto, make() as plain:
+        auto.set_bodies(b)
+        plain.set_bodies(b)
+        first = auto.order().copy()
+        auto.update(300)
+        for _ in range(300):
+            plain.step_local()
+            plain.step_finish()
+        got, ref = auto.read_bodies(), plain.read_bodies()
+        assert not np.array_equal(first, auto.order())
+        assert np.array_equal(first, plain.order())
+    # (the 64-body groups of the traversal differ after the renewal: FP32 summation order)
+    assert np.linalg.norm(got["pos"] - ref["pos"], axis=1).max() <= 1e-6 * np.abs(ref["pos"]).max()
