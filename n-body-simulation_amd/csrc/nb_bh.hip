@@ -1977,9 +1977,11 @@ __global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 
     uint4(*batch)[2] = st_batch[w];
 
     const int ntarget = a.tlist ? (int)*a.tcount : a.n;
-    const int slot = (blockIdx.x * TR_WPB + w) * 64 + lane;
+    // neighbouring groups of bodies visit mostly the same nodes: give them to one XCD's L2
+    const int wave = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * TR_WPB + w;
+    const int slot = wave * 64 + lane;
     const bool valid = slot < ntarget;
-    if ((blockIdx.x * TR_WPB + w) * 64 >= ntarget)
+    if (wave * 64 >= ntarget)
         return;  // whole wave idle (no block barriers below)
     const int k = valid ? (a.tlist ? (int)a.tlist[slot] : slot) : 0;
     const uint32_t body = a.idx[k];

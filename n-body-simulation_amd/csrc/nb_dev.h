@@ -1,6 +1,10 @@
 // nb_dev.h -- device helpers shared by the Barnes-Hut sources (2-D and 3-D).
 #pragma once
 
+#ifndef NB_XCD_REMAP
+#define NB_XCD_REMAP 1
+#endif
+
 #include <hip/hip_runtime.h>
 
 namespace nb {
@@ -60,6 +64,20 @@ static __host__ __device__ __forceinline__ int sort_first_pass(int used_bits)
 {
     const int p = (64 - used_bits) / 8;
     return p < 7 ? p : 7;
+}
+
+// Workgroups are dealt to the eight XCDs round-robin (blockIdx % 8 labels the blocks that share an
+// XCD and its L2).  This bijection hands every XCD a CONTIGUOUS eighth of the logical block range,
+// so that blocks working on neighbouring data share an L2.  Placement is a speed matter only.
+static __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t orig, uint32_t nblocks)
+{
+#if NB_XCD_REMAP
+    const uint32_t q = nblocks >> 3, r = nblocks & 7u, x = orig & 7u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (orig >> 3);
+#else
+    (void)nblocks;
+    return orig;
+#endif
 }
 
 }  // namespace nb
