@@ -1408,9 +1408,11 @@ __device__ __forceinline__ PyrCell pyr_load(const ComArgs &a, const uint4 *node_
 // the leaf pass left per 64-body chunk: the chunk where the run starts at the run's first position,
 // every later chunk in its own first slot.  A thread adds up to LEAF_SEQ later chunks itself
 // (leaves of ~130 bodies are the rule); a longer run -- the core of a collapsed disc puts tens of
-// thousands of bodies into one cell -- is left to pyr_long_sums.  The order of the additions
-// depends on the positions alone.
-constexpr uint32_t LEAF_SEQ = 8;
+// thousands of bodies into one cell -- is left to pyr_long_sums, a wave per run.  (With 8 instead of
+// 64 the block that owns the core of a collapsed disc, 256 cells of a few thousand bodies each, had
+// its four waves walk 64 such runs one after the other: k_pyr_sub 0.10 ms instead of 0.03.)  The
+// order of the additions depends on the positions alone.
+constexpr uint32_t LEAF_SEQ = 64;
 
 __device__ __forceinline__ bool pyr_short_sums(const double *leaf_sum, uint32_t first, uint32_t end, double (&out)[4])
 {
@@ -1425,13 +1427,23 @@ __device__ __forceinline__ bool pyr_short_sums(const double *leaf_sum, uint32_t 
     out[3] = v.y;
     if (cl - c0 > LEAF_SEQ)
         return true;  // the later chunks are still to be added
-    for (uint32_t cc = c0 + 1u; cc <= cl; ++cc) {
-        const double2 *q = (const double2 *)leaf_sum + 2 * ((size_t)cc << 6);
-        const double2 uu = q[0], vv = q[1];
-        out[0] += uu.x;
-        out[1] += uu.y;
-        out[2] += vv.x;
-        out[3] = fmax(out[3], vv.y);
+    // four chunks' parts in flight at a time, added in chunk order
+    for (uint32_t cc = c0 + 1u; cc <= cl; cc += 4u) {
+        double2 uu[4], vv[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) {
+            const double2 *q = (const double2 *)leaf_sum + 2 * ((size_t)(cc + i <= cl ? cc + i : cl) << 6);
+            uu[i] = q[0];
+            vv[i] = q[1];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i)
+            if (cc + i <= cl) {
+                out[0] += uu[i].x;
+                out[1] += uu[i].y;
+                out[2] += vv[i].x;
+                out[3] = fmax(out[3], vv[i].y);
+            }
     }
     return false;
 }
@@ -1703,6 +1715,23 @@ __global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, co
     const uint32_t nroots = 1u << (2 * r), nleaf = 1u << (2 * sub);
     const double width0 = a.box[2] - a.box[0];
     for (uint32_t root = blockIdx.x; root < nroots; root += gridDim.x) {
+        if (!CELLS) {
+            // A block whose cell holds no body (outliers stretch the box: most cells of a collapsed
+            // system's level 6 are empty) only marks its cells as empty.
+            bool any = false;
+            for (uint32_t t = threadIdx.x; t < nleaf; t += 256) {
+                const uint2 range = pc_range[root * nleaf + t];
+                any = any || range.y > range.x;
+            }
+            if (!__syncthreads_or(any)) {
+                for (int k = sub; k >= 0; --k) {
+                    const uint32_t cnt = 1u << (2 * k);
+                    for (uint32_t t = threadIdx.x; t < cnt; t += 256)
+                        node_meta[pyr_offset(r + k) + root * cnt + t] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                continue;
+            }
+        }
         for (uint32_t t0 = 0; t0 < nleaf; t0 += 256) {
             const uint32_t t = t0 + threadIdx.x;
             const bool mine = t < nleaf;
@@ -1978,7 +2007,7 @@ __global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 
 
     const int ntarget = a.tlist ? (int)*a.tcount : a.n;
     // neighbouring groups of bodies visit mostly the same nodes: give them to one XCD's L2
-    const int wave = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * TR_WPB + w;
+    const int wave = (int)xcd_chunked_block(blockIdx.x, gridDim.x) * TR_WPB + w;
     const int slot = wave * 64 + lane;
     const bool valid = slot < ntarget;
     if (wave * 64 >= ntarget)

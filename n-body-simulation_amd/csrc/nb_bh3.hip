@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * TR3_WPB) void k_bh3_force(Force3Args a)
     float *bprune = st_prune[w];
 
     const int ntarget = a.tlist ? (int)*a.tcount : a.n;
-    const int wave = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * TR3_WPB + w;  // see k_bh_force
+    const int wave = (int)xcd_chunked_block(blockIdx.x, gridDim.x) * TR3_WPB + w;  // see k_bh_force
     const int slot = wave * 64 + lane;
     if (wave * 64 >= ntarget)
         return;  // whole wave idle (no block barriers below)

@@ -1,10 +1,6 @@
 // nb_dev.h -- device helpers shared by the Barnes-Hut sources (2-D and 3-D).
 #pragma once
 
-#ifndef NB_XCD_REMAP
-#define NB_XCD_REMAP 1
-#endif
-
 #include <hip/hip_runtime.h>
 
 namespace nb {
@@ -67,17 +63,20 @@ static __host__ __device__ __forceinline__ int sort_first_pass(int used_bits)
 }
 
 // Workgroups are dealt to the eight XCDs round-robin (blockIdx % 8 labels the blocks that share an
-// XCD and its L2).  This bijection hands every XCD a CONTIGUOUS eighth of the logical block range,
-// so that blocks working on neighbouring data share an L2.  Placement is a speed matter only.
-static __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t orig, uint32_t nblocks)
-{
-#if NB_XCD_REMAP
-    const uint32_t q = nblocks >> 3, r = nblocks & 7u, x = orig & 7u;
-    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (orig >> 3);
-#else
-    (void)nblocks;
-    return orig;
+// XCD and its L2).  This bijection hands every XCD runs of NB_XCD_CHUNK consecutive logical blocks,
+// so that blocks working on neighbouring data share an L2, while every XCD still gets its share of
+// every part of the range (a contiguous eighth per XCD leaves the XCD that owns a dense region behind
+// the others).  Placement is a speed matter only.
+#ifndef NB_XCD_CHUNK
+#define NB_XCD_CHUNK 32
 #endif
+static __device__ __forceinline__ uint32_t xcd_chunked_block(uint32_t orig, uint32_t nblocks)
+{
+    constexpr uint32_t C = NB_XCD_CHUNK;
+    if (C <= 1u || orig >= nblocks - nblocks % (8u * C))
+        return orig;  // the last, partial round of chunks stays as dealt
+    const uint32_t x = orig & 7u, q = orig >> 3;
+    return ((q / C) * 8u + x) * C + q % C;
 }
 
 }  // namespace nb

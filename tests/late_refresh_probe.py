@@ -27,4 +27,6 @@ with nb.NBodySim(n, nb.BARNES_HUT) as sim:
     sim.update(3)
     timed("steps 3-13")
     sim.update(late - 13)
+    if "renew" in sys.argv:
+        sim.refresh_order()
     timed("steps %d-%d" % (late, late + 10))
