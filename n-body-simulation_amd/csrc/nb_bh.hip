@@ -86,9 +86,14 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const double2 *pos, int n,
 // of all ranks' bodies (minima negated so that one max-reduction serves), and the keys get
 // cells_levels digits whatever level closes the tree (cut[4]); a tree that closes deeper than that
 // cannot be exchanged at this level: *err is set.
+constexpr int SORT_PACK_LEVELS = 15;        // key digits that leave bits 31..0 of the key word zero
+constexpr int SORT_PACK_MAX_N = 1 << 30;    // the index stays below bit 30, the lowest bit a sort pass with work reads
+constexpr uint32_t SORT_PACK_MASK = (1u << 30) - 1u;
+
 __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk, double margin, int bucket_depth,
                                                     double theta, double cth, double *box, uint32_t *cut, int pyr_levels,
-                                                    uint32_t *hint_host, double *hint_box, int cells_levels, uint32_t *err)
+                                                    uint32_t *hint_host, double *hint_box, int cells_levels, uint32_t *err,
+                                                    int n)
 {
     double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
     for (int i = threadIdx.x; i < nblk; i += 256) {
@@ -168,6 +173,9 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
             if (first_closed > (uint32_t)cells_levels && err)
                 *err = 1u;
         }
+        // Keys of at most 15 digits leave the low 32 bits of the key word free: the body's index (below 2^30)
+        // travels there through the sort instead of in an array of its own (see k_sort_scatter).
+        cut[5] = (cut[1] <= (uint32_t)SORT_PACK_LEVELS && n <= SORT_PACK_MAX_N) ? 1u : 0u;
         if (hint_host)
             *hint_host = cut[4];  // host-visible: sizes the next steps' launches (a stale value only costs speed)
         if (hint_box) {           // host-visible: width and height of the box
@@ -214,7 +222,8 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     b.use_pyr = hint <= (uint32_t)PYR_MAX_LEVEL;
     b.pyr_levels = b.use_pyr ? PYR_MAX_LEVEL : -1;  // the deepest key level the pyramid kernels can do
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, a.bucket_depth,
-                       a.theta, a.collision_th, b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, -1, (uint32_t *)nullptr);
+                       a.theta, a.collision_th, b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, -1, (uint32_t *)nullptr,
+                       a.n);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -256,7 +265,12 @@ __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const d
         k = (k << 2) | ((uint64_t)below << 1) | (uint64_t)right;
     }
     const bool odd = cut[2] & 1u;
-    (odd ? keys1 : keys0)[i] = levels > 0 ? k << (2 * (BH_KEY_LEVELS - levels)) : 0ull;
+    const uint64_t key = levels > 0 ? k << (2 * (BH_KEY_LEVELS - levels)) : 0ull;
+    if (cut[5] != 0u) {
+        (odd ? keys1 : keys0)[i] = key | (uint64_t)(uint32_t)i;  // the index rides in the key's free low bits
+        return;
+    }
+    (odd ? keys1 : keys0)[i] = key;
     (odd ? idx1 : idx0)[i] = (uint32_t)i;
 }
 
@@ -447,6 +461,10 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
     __shared__ uint64_t lkey[SORT_TILE];
     __shared__ uint32_t lval[SORT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // packed: the values are the low 30 bits of the keys (no pass with work reads those bits); they
+    // are moved with the keys, and the last pass takes the pairs apart again
+    const bool packed = cut[5] != 0u;
+    const bool unpack = packed && pass == SORT_PASSES - 1;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         wcnt[k][tid] = 0;
@@ -463,7 +481,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
         const int i = chunk + it * 64 + lane;
         const bool valid = i < n;
         key[it] = valid ? keys_in[i] : ~0ull;
-        val[it] = valid ? idx_in[i] : 0u;
+        val[it] = (valid && !packed) ? idx_in[i] : 0u;
         const uint32_t d = sort_digit(key[it], pass);
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -511,7 +529,8 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
             const uint32_t d = sort_digit(key[it], pass);
             const uint32_t p = lstart[d] + wcnt[w][d] + rank[it];
             lkey[p] = key[it];
-            lval[p] = val[it];
+            if (!packed)
+                lval[p] = val[it];
         }
     }
     __syncthreads();
@@ -521,8 +540,11 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
         const uint64_t k = lkey[t];
         const uint32_t d = sort_digit(k, pass);
         const uint32_t dst = dbase[d] + (uint32_t)t;
-        keys_out[dst] = k;
-        idx_out[dst] = lval[t];
+        keys_out[dst] = unpack ? k & ~(uint64_t)SORT_PACK_MASK : k;
+        if (!packed)
+            idx_out[dst] = lval[t];
+        else if (unpack)
+            idx_out[dst] = (uint32_t)k & SORT_PACK_MASK;
     }
 }
 
@@ -2535,7 +2557,7 @@ int bh_cells_middle(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_
         b.pyr_levels = PYR_MAX_LEVEL;
         b.sorted = 0;
         hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.red4, 1, a.bbox_margin, 0, a.theta, a.collision_th,
-                           b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, cells_levels, b.err_host);
+                           b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, cells_levels, b.err_host, a.n);
         NB_HIP(hipGetLastError());
         return a.n > 0 ? bh_keys(s, b, a) : (int)NB_OK;
     }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_bbox3_partial(const double *pos, int n,
 }
 
 __global__ __launch_bounds__(256) void k_bbox3_final(const double *part, int nblk, double margin, double theta, double cth,
-                                                     double *box, uint32_t *cut)
+                                                     double *box, uint32_t *cut, int n)
 {
     MinMax3 m;
     mm_init(m);
@@ -127,6 +127,9 @@ __global__ __launch_bounds__(256) void k_bbox3_final(const double *part, int nbl
         cut[0] = first_closed;
         cut[1] = first_closed < (uint32_t)BH3_KEY_LEVELS ? first_closed : (uint32_t)BH3_KEY_LEVELS;
         cut[2] = (uint32_t)sort_first_pass(3 * (int)cut[1]);
+        // keys of at most 10 digits leave the low 32 bits of the key word free for the body's index
+        // (see k_sort_scatter in nb_bh.hip)
+        cut[5] = (cut[1] <= 10u && n <= (1 << 30)) ? 1u : 0u;
     }
 }
 
@@ -137,7 +140,7 @@ int bh3_bbox(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
         blocks = BBOX3_BLOCKS;
     hipLaunchKernelGGL(k_bbox3_partial, dim3(blocks), dim3(256), 0, s, a.pos, a.n, b.bbox_part);
     hipLaunchKernelGGL(k_bbox3_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, a.theta, a.collision_th,
-                       b.box, b.cut);
+                       b.box, b.cut, a.n);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -171,7 +174,12 @@ __global__ __launch_bounds__(256) void k_keys3(const double *pos, int n, const d
         k = (k << 3) | ((uint64_t)zlow << 2) | ((uint64_t)ylow << 1) | (uint64_t)right;
     }
     const bool odd = cut[2] & 1u;
-    (odd ? keys1 : keys0)[i] = levels > 0 ? k << (2 + 3 * (BH3_KEY_LEVELS - levels)) : 0ull;
+    const uint64_t key = levels > 0 ? k << (2 + 3 * (BH3_KEY_LEVELS - levels)) : 0ull;
+    if (cut[5] != 0u) {
+        (odd ? keys1 : keys0)[i] = key | (uint64_t)(uint32_t)i;  // the index rides in the key's free low bits
+        return;
+    }
+    (odd ? keys1 : keys0)[i] = key;
     (odd ? idx1 : idx0)[i] = (uint32_t)i;
 }
 
@@ -917,7 +925,7 @@ int bh3_alloc(Bh3Buffers &b, int n)
     b.n = n;
     b.node_cap = 2 * (size_t)n + 8;
     NB_TRY(dev_alloc(b.box, 6));
-    NB_TRY(dev_alloc(b.cut, 4));
+    NB_TRY(dev_alloc(b.cut, 8));
     NB_TRY(dev_alloc(b.bbox_part, 6 * BBOX3_BLOCKS));
     for (int k = 0; k < 2; ++k) {
         NB_TRY(dev_alloc(b.keys[k], (size_t)n));

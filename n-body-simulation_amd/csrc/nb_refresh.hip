@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_rf_minmax(const double *pos, int n, dou
 
 // One block: the box of all bodies, the sort's first pass, and the middle of the box for the host.
 template <int DIMS>
-__global__ __launch_bounds__(256) void k_rf_box(const double *part, int nblk, double *box, uint32_t *cut, double *origin_host)
+__global__ __launch_bounds__(256) void k_rf_box(const double *part, int nblk, double *box, uint32_t *cut, double *origin_host, int n)
 {
     __shared__ double sh[256][2 * DIMS];
     double v[2 * DIMS];
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void k_rf_box(const double *part, int nblk, do
         cut[1] = 16u;
         cut[2] = 4u;  // the codes fill the top 32 bits of the sorted word: passes 4..7 have work
         cut[3] = 0u;
+        cut[5] = n <= (1 << 30) ? 1u : 0u;  // the index rides in the 30 bits below the code (k_sort_scatter in nb_bh.hip)
     }
 }
 
@@ -130,7 +131,11 @@ __global__ __launch_bounds__(256) void k_rf_keys(const double *pos, int n, const
             code |= spread3((uint64_t)((pos[3 * (size_t)i + d] - box[d]) * sc)) << d;
         code <<= 2;  // 30 bits, at the top of the 32
     }
-    keys[i] = code << 30;  // sort_pairs orders key << 2
+    if (n <= (1 << 30)) {
+        keys[i] = (code << 30) | (uint64_t)(uint32_t)i;  // sort_pairs orders key << 2; packed (k_rf_box's cut[5])
+        return;
+    }
+    keys[i] = code << 30;
     idx[i] = (uint32_t)i;
 }
 
@@ -157,7 +162,7 @@ int refresh_alloc(RefreshBuffers &r, int n)
     }
     NB_TRY(dev_alloc(r.hist, sort_hist_words(n)));
     NB_TRY(dev_alloc(r.totals, 256));
-    NB_TRY(dev_alloc(r.cut, 4));
+    NB_TRY(dev_alloc(r.cut, 8));
     NB_TRY(dev_alloc(r.part, (size_t)RF_BLOCKS * 6));
     NB_TRY(dev_alloc(r.box, 6));
     char *t = nullptr;
@@ -198,11 +203,11 @@ int refresh_sort(hipStream_t s, RefreshBuffers &r, const double *pos, int dims, 
     const dim3 grid((n + 255) / 256);
     if (dims == 2) {
         hipLaunchKernelGGL(k_rf_minmax<2>, dim3(blocks), dim3(256), 0, s, pos, n, r.part);
-        hipLaunchKernelGGL(k_rf_box<2>, dim3(1), dim3(256), 0, s, r.part, blocks, r.box, r.cut, r.origin_host);
+        hipLaunchKernelGGL(k_rf_box<2>, dim3(1), dim3(256), 0, s, r.part, blocks, r.box, r.cut, r.origin_host, n);
         hipLaunchKernelGGL(k_rf_keys<2>, grid, dim3(256), 0, s, pos, n, r.box, r.keys[0], r.idx[0]);
     } else {
         hipLaunchKernelGGL(k_rf_minmax<3>, dim3(blocks), dim3(256), 0, s, pos, n, r.part);
-        hipLaunchKernelGGL(k_rf_box<3>, dim3(1), dim3(256), 0, s, r.part, blocks, r.box, r.cut, r.origin_host);
+        hipLaunchKernelGGL(k_rf_box<3>, dim3(1), dim3(256), 0, s, r.part, blocks, r.box, r.cut, r.origin_host, n);
         hipLaunchKernelGGL(k_rf_keys<3>, grid, dim3(256), 0, s, pos, n, r.box, r.keys[0], r.idx[0]);
     }
     NB_HIP(hipGetLastError());
