@@ -47,6 +47,28 @@ def main():
         h, m = cs.get("TCC_HIT_sum"), cs.get("TCC_MISS_sum")
         if h and m:
             summary[k]["l2_hit_rate"] = sum(h) / (sum(h) + sum(m))
+    # instructions per node visit of the traversal: the counters of its plain instantiation over the
+    # wave-node visits the bench counted for the same workload (its statistics run), this round and,
+    # for comparison, the committed figures of the round before
+    def per_visit(counters, bench_line):
+        visits = (bench_line.get("tree") or {}).get("group_node_visits")
+        if not visits:
+            return None
+        return {c.replace("SQ_INSTS_", "").lower(): counters[c]["mean"] / visits
+                for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in counters} | {"wave_node_visits": visits}
+
+    plain = [k for k in summary if k.startswith("k_bh_force<") and "false" in k]
+    if plain:
+        line = json.loads(open(os.path.join(src, "bench.json")).read().strip().split("\n")[-1])
+        summary["k_bh_force_per_visit"] = {rnd: per_visit(summary[plain[0]], line)}
+        prev = "r%02d" % (int(rnd[1:]) - 1)
+        try:
+            old = json.load(open(os.path.join(out, prev + "_pmc.json")))
+            old_line = json.loads(open(os.path.join(out, prev + "_bench.json")).read().strip().split("\n")[-1])
+            old_plain = [k for k in old if k.startswith("k_bh_force<") and "false" in k]
+            summary["k_bh_force_per_visit"][prev] = per_visit(old[old_plain[0]], old_line)
+        except (OSError, ValueError, IndexError, KeyError):
+            pass
     json.dump(summary, open(os.path.join(out, rnd + "_pmc.json"), "w"), indent=1, sort_keys=True)
     traffic = {}
     # the traversal instantiation the bench ran most often (the other is its statistics variant)
