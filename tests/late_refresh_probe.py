@@ -26,7 +26,10 @@ with nb.NBodySim(n, nb.BARNES_HUT) as sim:
 
     sim.update(3)
     timed("steps 3-13")
-    sim.update(late - 13)
+    for done in range(13, late, 50):  # (in pieces, with a sign of life: under a profiler this takes a while)
+        sim.update(min(50, late - done))
+        sim.sync()
+        print("  at step %d" % min(late, done + 50), flush=True)
     if "renew" in sys.argv:
         sim.refresh_order()
     timed("steps %d-%d" % (late, late + 10))
