@@ -63,6 +63,7 @@ struct BhBuffers {
     uint32_t *err = nullptr;          // (unused device word kept beside them)
     bool use_pyr = false;             // this step's kernels are launched for the dense-pyramid build ...
     int pyr_levels = -1;              // ... and can do keys of up to this many levels (-1: not launched)
+    int sort_first = 0;               // the first sort pass this step's launches include
 };
 
 int bh_alloc(BhBuffers &b, int n);
@@ -97,7 +98,8 @@ struct BhStepArgs {
 // the result is in buffer 0.  cut[2] = first pass with work (sort_first_pass in nb_dev.h); the
 // unsorted pairs must be in buffer cut[2] & 1.  hist: sort_hist_words(n) words, totals: 256.
 // first_launch: passes below it are not even launched -- only for a caller that chose the key width
-// itself and so knows that cut[2] >= first_launch; 0 launches all eight (the device decides).
+// itself and so knows that cut[2] >= first_launch, or that makes the device keep cut[2] at or above
+// it (bh_sort); 0 launches all eight (the device decides).
 int sort_blocks(int n);
 size_t sort_hist_words(int n);
 int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], int n, const uint32_t *cut, uint32_t *hist,

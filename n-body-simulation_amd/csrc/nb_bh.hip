@@ -93,7 +93,7 @@ constexpr uint32_t SORT_PACK_MASK = (1u << 30) - 1u;
 __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk, double margin, int bucket_depth,
                                                     double theta, double cth, double *box, uint32_t *cut, int pyr_levels,
                                                     uint32_t *hint_host, double *hint_box, int cells_levels, uint32_t *err,
-                                                    int n)
+                                                    int n, int sort_first)
 {
     double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
     for (int i = threadIdx.x; i < nblk; i += 256) {
@@ -176,6 +176,12 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         // Keys of at most 15 digits leave the low 32 bits of the key word free: the body's index (below 2^30)
         // travels there through the sort instead of in an array of its own (see k_sort_scatter).
         cut[5] = (cut[1] <= (uint32_t)SORT_PACK_LEVELS && n <= SORT_PACK_MAX_N) ? 1u : 0u;
+        // The host launches the sort's passes from sort_first on (it sizes them by the keys of the
+        // last step it knows): cut[2] becomes the first pass that RUNS, cut[7] keeps the first the
+        // keys NEED; if that is lower, k_sort_fix finishes the order.
+        cut[7] = cut[2];
+        if (cut[2] < (uint32_t)sort_first)
+            cut[2] = (uint32_t)sort_first;
         if (hint_host)
             *hint_host = cut[4];  // host-visible: sizes the next steps' launches (a stale value only costs speed)
         if (hint_box) {           // host-visible: width and height of the box
@@ -221,9 +227,17 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     const uint32_t hint = (b.pc_range && b.hint_host) ? *(volatile const uint32_t *)b.hint_host : 0xffffffffu;
     b.use_pyr = hint <= (uint32_t)PYR_MAX_LEVEL;
     b.pyr_levels = b.use_pyr ? PYR_MAX_LEVEL : -1;  // the deepest key level the pyramid kernels can do
+    // The sort's passes below the keys' digits would return at once, at a launch each: they are
+    // not launched, with one pass to spare below what the last known keys needed.
+    b.sort_first = 0;
+    if (hint <= (uint32_t)BH_KEY_LEVELS) {
+        b.sort_first = sort_first_pass(2 * (int)hint) - 1;
+        if (b.sort_first < 0)
+            b.sort_first = 0;
+    }
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, a.bucket_depth,
                        a.theta, a.collision_th, b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, -1, (uint32_t *)nullptr,
-                       a.n);
+                       a.n, b.sort_first);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -555,8 +569,9 @@ int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], i
                uint32_t *totals, int first_launch)
 {
     const int nblk = sort_blocks(n);
-    // first_launch > 0: the caller KNOWS cut[2] >= first_launch (it chose the key width itself); the
-    // passes below it would return at once, at a launch each
+    // first_launch > 0: cut[2] >= first_launch holds on the device -- the caller chose the key width
+    // itself, or had k_bbox_final raise cut[2] to it and repairs the order afterwards (k_sort_fix);
+    // the passes below it would return at once, at a launch each
     for (int pass = first_launch; pass < SORT_PASSES; ++pass) {
         const int in = pass & 1, out = in ^ 1;
         hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, s, keys[in], n, pass, cut, hist, nblk);
@@ -569,10 +584,52 @@ int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], i
     return NB_OK;
 }
 
+// When the keys of a step need sort passes below the ones the host launched for it (it only knew
+// the keys of an earlier step: cut[7] < cut[2]), the pairs come out ordered by the key bits the
+// launched passes cover -- runs of equal upper bits, inside which the input order is kept.  The
+// thread of a run's first pair then sorts the run by the whole key, stably, by insertion: together
+// that is the order the full sort gives.  Runs are bodies that share a cell at least four levels
+// below the deepest the host expected, i.e. short; this is the rare step in which the bounding box
+// has outgrown that by a factor of 16 since the host last looked, and the next steps are launched
+// for the new depth.
+__global__ __launch_bounds__(256) void k_sort_fix(uint64_t *keys, uint32_t *idx, int n, const uint32_t *cut)
+{
+    if (cut[7] >= cut[2])
+        return;  // every pass the keys need was launched
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const int shift = (int)cut[2] * SORT_BITS - 2;  // the launched passes ordered key bits [shift, 62)
+    const uint64_t pre = keys[i] >> shift;
+    // (a neighbouring run's thread may be moving its pairs meanwhile: they keep their upper bits)
+    if (i > 0 && (keys[i - 1] >> shift) == pre)
+        return;  // not the first pair of a run
+    int end = i + 1;
+    while (end < n && (keys[end] >> shift) == pre)
+        ++end;
+    for (int a = i + 1; a < end; ++a) {
+        const uint64_t ka = keys[a];
+        const uint32_t va = idx[a];
+        int at = a;
+        while (at > i && keys[at - 1] > ka) {
+            keys[at] = keys[at - 1];
+            idx[at] = idx[at - 1];
+            --at;
+        }
+        keys[at] = ka;
+        idx[at] = va;
+    }
+}
+
 int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     b.sorted = 0;
-    return sort_pairs(s, b.keys, b.idx, a.n, b.cut, b.hist, b.hist_totals);
+    NB_TRY(sort_pairs(s, b.keys, b.idx, a.n, b.cut, b.hist, b.hist_totals, b.sort_first));
+    if (b.sort_first > 0) {
+        hipLaunchKernelGGL(k_sort_fix, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[0], b.idx[0], a.n, b.cut);
+        NB_HIP(hipGetLastError());
+    }
+    return NB_OK;
 }
 
 // ------------------------------------------------------------------ 4 tree build
@@ -2557,7 +2614,7 @@ int bh_cells_middle(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_
         b.pyr_levels = PYR_MAX_LEVEL;
         b.sorted = 0;
         hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.red4, 1, a.bbox_margin, 0, a.theta, a.collision_th,
-                           b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, cells_levels, b.err_host, a.n);
+                           b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, cells_levels, b.err_host, a.n, 0);
         NB_HIP(hipGetLastError());
         return a.n > 0 ? bh_keys(s, b, a) : (int)NB_OK;
     }

@@ -662,3 +662,31 @@ def test_long_tree_run_renews_its_order_by_itself(nb, oracle, dims):
         assert np.array_equal(first, plain.order())
     # (the 64-body groups of the traversal differ after the renewal: FP32 summation order)
     assert np.linalg.norm(got["pos"] - ref["pos"], axis=1).max() <= 1e-6 * np.abs(ref["pos"]).max()
+
+
+@pytest.mark.parametrize("speed", [2.5e10, 1.0e12])
+def test_sort_is_finished_when_the_keys_outgrow_the_launched_passes(nb, oracle, speed):
+    """The host launches only the sort passes the keys of the last step it knows needed, plus one
+    below.  A body leaving at an absurd speed widens the box hundreds (or tens of thousands) of
+    times within one step: the keys of the next evaluation need passes that were not launched, and
+    the device finishes the order itself.  Keys and sorted order must be the reference's to the bit
+    (the accelerations cannot be checked at the usual bar: float coordinates no longer resolve the
+    system inside such a box)."""
+    n = 20000
+    b = nb.init_scenario(nb.SPIRAL, n, 9)
+    b["vel"][11] = (speed, -0.4 * speed)
+    with nb.NBodySim(n, nb.BARNES_HUT) as sim:
+        sim.set_bodies(b)
+        sim.compute_accel()
+        before = int(sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2)[1])
+        sim.update(1)  # launched for the depth above; moves the body away
+        for _ in range(2):  # the first evaluation is still launched for the old depth, the second for the new
+            sim.compute_accel()
+            state = exchange_bodies(sim, sim.read_bodies())
+            box = sim.debug(nb.DBG_BBOX, np.float64, 4)
+            assert np.array_equal(box, oracle.bh_bbox(state))
+            ref_keys, levels = cut_keys(nb, sim, oracle.morton_keys(state, box))
+            order = np.argsort(ref_keys, kind="stable")
+            assert np.array_equal(sim.debug(nb.DBG_SORTED_KEYS, np.uint64, n), ref_keys[order])
+            assert np.array_equal(sim.debug(nb.DBG_SORTED_IDX, np.uint32, n), order.astype(np.uint32))
+    assert before <= 10 and levels >= before + 8, (before, levels)
