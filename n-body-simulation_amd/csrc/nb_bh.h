@@ -35,7 +35,6 @@ struct BhBuffers {
     double *leaf_sum = nullptr;   // 4 doubles per sorted body: sums over the run of equal keys starting there
     uint32_t *chunk_info = nullptr;  // per 64 sorted bodies: first lane that starts a run (64: none) |
                                      // lane where the run that goes on into the next chunk starts (0xff: none) << 8
-    float4 *posm_s = nullptr;     // per sorted body {x, y, m, radius} in internal units
     uint4 *node_meta = nullptr;   // first body, body count, first child, child count | cell level << 8
     uint4 *split = nullptr;       // per frontier slot: the three quadrant boundaries and child count
     uint32_t *level_start = nullptr;  // BH_MAX_DEPTH + 2 entries

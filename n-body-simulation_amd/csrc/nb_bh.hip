@@ -1053,7 +1053,6 @@ struct ComArgs {
     const uint32_t *idx;
     const double2 *pos;
     const double2 *mass_radius;
-    const float4 *posm_s;
     const double *box;
     double *node_com;
     float4 *node_rec;
@@ -1066,6 +1065,15 @@ struct ComArgs {
     double inv_len, inv_mass, theta, cth;
     int bucket;  // leaves are point masses judged like cells (the GPU program's tree)
 };
+
+// Traversal record of a leaf that holds one body: its position relative to the step's origin and
+// its mass in internal units, and minus its pair cutoff radius + collision_th (the sign marks a body).
+__device__ __forceinline__ float4 body_record(const ComArgs &a, double2 p, double2 mass_radius)
+{
+    const double ox = 0.5 * (a.box[0] + a.box[2]), oy = 0.5 * (a.box[1] + a.box[3]);
+    return make_float4((float)((p.x - ox) * a.inv_len), (float)((p.y - oy) * a.inv_len), (float)(mass_radius.x * a.inv_mass),
+                       -(float)((mass_radius.y + a.cth) * a.inv_len));
+}
 
 // Traversal record, width and prune threshold of a cell of level lvl with the given centre of mass.
 __device__ __forceinline__ void cell_record(const ComArgs &a, double cx, double cy, double mtot, int lvl, double width0,
@@ -1128,14 +1136,10 @@ __device__ __forceinline__ void store_node(const ComArgs &a, uint32_t u, const u
 // starts at the run's first position, the others in their own first slot) and k_leaf_finish adds
 // them up.  The order of the additions is fixed by the positions alone, so the sums are
 // reproducible.
-// The same pass writes every body's float record {x, y, m, radius} in sorted order (the
-// traversal's targets and the one-body leaves), since it reads exactly what that needs.
 __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const uint32_t *idx, int n, const double2 *pos,
-                                                   const double2 *mass_radius, const double *box,
-                                                   double inv_len, double inv_mass, float4 *posm_s, double *leaf_sum,
-                                                   uint32_t *chunk_info, const uint32_t *cut, uint2 *pc_range)
+                                                   const double2 *mass_radius, double *leaf_sum, uint32_t *chunk_info,
+                                                   const uint32_t *cut, uint2 *pc_range)
 {
-    const double ox = 0.5 * (box[0] + box[2]), oy = 0.5 * (box[1] + box[3]);  // this step's origin
     const int lane = lane_id();
     const int chunk = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     if (chunk >= n)
@@ -1153,8 +1157,6 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
         sx = p.x * sm;
         sy = p.y * sm;
         rm = mr.y;
-        posm_s[k] = make_float4((float)((p.x - ox) * inv_len), (float)((p.y - oy) * inv_len), (float)(sm * inv_mass),
-                                (float)(rm * inv_len));
     }
     const bool head = valid && (k == 0 || key != prev);
     const uint64_t heads = __builtin_amdgcn_ballot_w64(head);
@@ -1375,8 +1377,7 @@ __device__ __forceinline__ void com_level(const ComArgs &a, int d)
                 cy = p.y;
                 const double2 mr = a.mass_radius[o];
                 mtot = mr.x;
-                const float4 pm = a.posm_s[first];
-                rec = make_float4(pm.x, pm.y, pm.z, -(float)((mr.y + a.cth) * a.inv_len));
+                rec = body_record(a, p, mr);
                 width = -mr.y;
                 if (a.bucket) {
                     rec.w = 0.f;  // see multi_body_record; the target's own leaf (distance 0) is
@@ -1587,8 +1588,7 @@ __device__ __forceinline__ PyrCell pyr_leaf(const ComArgs &a, uint32_t first, ui
         c.cy = p.y;
         const double2 mr = a.mass_radius[o];
         c.m = mr.x;
-        const float4 pm = a.posm_s[first];
-        c.rec = make_float4(pm.x, pm.y, pm.z, -(float)((mr.y + a.cth) * a.inv_len));
+        c.rec = body_record(a, p, mr);
         c.w = -mr.y;
         if (a.bucket) {
             c.rec.w = 0.f;
@@ -1938,7 +1938,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     const ComArgs c = com_args(b, a);
     hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[b.sorted], b.idx[b.sorted], a.n, a.pos,
-                       a.mass_radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum, b.chunk_info, b.cut, b.pc_range);
+                       a.mass_radius, b.leaf_sum, b.chunk_info, b.cut, b.pc_range);
     if (b.use_pyr) {
         // Two launches build the tree, the centres of mass and the traversal records (k_pyr_top also
         // holds the one-block fallback for keys deeper than these launches cover).
@@ -1976,7 +1976,6 @@ static ComArgs com_args(const BhBuffers &b, const BhStepArgs &a)
     c.idx = b.idx[b.sorted];
     c.pos = a.pos;
     c.mass_radius = a.mass_radius;
-    c.posm_s = b.posm_s;
     c.box = b.box;
     c.node_com = b.node_com;
     c.node_rec = b.node_rec;
@@ -2016,7 +2015,8 @@ constexpr int TR_STACK = TR_HIGH + TR_BATCH + 3 * 32 + 1;  // entries per wave
 static_assert(TR_ENTRIES >= 1 && TR_ENTRIES <= 16, "one group of 4 lanes per popped entry");
 
 struct ForceArgs {
-    const float4 *posm_s;
+    const double *box;       // this step's bounding box (the origin of the float coordinates is its middle)
+    double inv_len;          // 1 / length unit
     const float4 *node_rec;
     const uint2 *node_aux;   // x = first child slot << 4 | mask of the slots in use, y = float bits of the prune threshold
     const double *node_com;
@@ -2093,8 +2093,12 @@ __global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         return;  // whole wave idle (no block barriers below)
     const int k = valid ? (a.tlist ? (int)a.tlist[slot] : slot) : 0;
     const uint32_t body = a.idx[k];
-    const float4 me = a.posm_s[k];
-    const float xi = me.x, yi = me.y, ri = me.w;
+    const double2 pd = a.pos[body];
+    const double rd = a.radius[body];
+    // the target in the float coordinates of this step's records (ComArgs: relative to the middle of the box)
+    const float xi = (float)((pd.x - 0.5 * (a.box[0] + a.box[2])) * a.inv_len);
+    const float yi = (float)((pd.y - 0.5 * (a.box[1] + a.box[3])) * a.inv_len);
+    const float ri = (float)(rd * a.inv_len);
     const bool dynamic = valid && a.dyn[body];
     // BarnesHut::isCollide(Body, Vector): 2 r_i + th > dist drops an accepted cell (barnesHut.cpp:131-134)
     const float thn = 2.f * ri + a.fc.cth;
@@ -2104,8 +2108,6 @@ __global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 
     // must the zero distance be excluded explicitly
     const bool self_test = !(a.fc.cth > 0.f);
     const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
-    const double2 pd = a.pos[body];
-    const double rd = a.radius[body];
     // Bounding box of the wave's targets and their largest cell cutoff: a cell whose centre of
     // mass is farther from the box than that (with a margin far above float rounding) passes
     // the cutoff test for every lane and cannot be pruned.  A batch made of such cells only is
@@ -2498,7 +2500,8 @@ int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int
 int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     ForceArgs f;
-    f.posm_s = b.posm_s;
+    f.box = b.box;
+    f.inv_len = 1.0 / a.units.len_unit;
     f.node_rec = b.node_rec;
     f.node_aux = b.node_child;
     f.node_com = b.node_com;
@@ -2625,7 +2628,7 @@ int bh_cells_middle(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_
     const ComArgs c = com_args(b, a);
     if (a.n > 0) {
         hipLaunchKernelGGL(k_leaf_sums, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[0], b.idx[0], a.n, a.pos,
-                           a.mass_radius, b.box, c.inv_len, c.inv_mass, b.posm_s, b.leaf_sum, b.chunk_info, b.cut, b.pc_range);
+                           a.mass_radius, b.leaf_sum, b.chunk_info, b.cut, b.pc_range);
     } else {
         // no own bodies: every cell slot reads as empty
         NB_HIP(hipMemsetAsync(b.pc_range, 0, sizeof(uint2) << (2 * cells_levels), s));
@@ -2674,7 +2677,6 @@ static int bh_layout(BhBuffers &b, int n, bool with_pyramid, Alloc &&alloc)
     }
     NB_TRY(alloc(b.hist, (size_t)SORT_BINS * b.sort_blocks));
     NB_TRY(alloc(b.hist_totals, SORT_BINS));
-    NB_TRY(alloc(b.posm_s, (size_t)n));
     NB_TRY(alloc(b.node_meta, b.node_cap));
     NB_TRY(alloc(b.split, (size_t)n + 256));  // one Split<2> (16 bytes) per frontier slot
     NB_TRY(alloc(b.level_start, BH_MAX_DEPTH + 2));
@@ -2752,7 +2754,6 @@ void bh_free(BhBuffers &b)
         }
         (void)hipFree(b.hist);
         (void)hipFree(b.hist_totals);
-        (void)hipFree(b.posm_s);
         (void)hipFree(b.node_meta);
         (void)hipFree(b.split);
         (void)hipFree(b.level_start);
