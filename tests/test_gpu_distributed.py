@@ -121,6 +121,27 @@ def test_native_rccl_world1_matches_plain_update(nb, oracle, alg, dims):
     assert ms["force"] > 0 and ms["exchange"] >= 0
 
 
+@pytest.mark.parametrize("dims", [2, 3])
+def test_native_rccl_world1_renews_the_order_like_the_plain_run(nb, oracle, dims):
+    """nb_step_distributed crosses the Barnes-Hut order renewal (every 256 steps: one more all-gather,
+    of the velocities, then the renewal on the device) exactly as nb_step does."""
+    n = 2000
+    b = oracle.scenario(0, n, 6) if dims == 2 else oracle.scenario3(0, n, 6, thickness=5.0e10)
+    Sim = nb.NBodySim if dims == 2 else nb.NBodySim3
+    with Sim(n, nb.BARNES_HUT) as plain, Sim(n, nb.BARNES_HUT) as part:
+        plain.set_bodies(b)
+        part.set_bodies(b)
+        part.comm_init(0, 1, nb.comm_unique_id())
+        first = part.order().copy()
+        plain.update(260)
+        part.step_distributed(260)
+        a, ref = part.read_bodies(), plain.read_bodies()
+        assert not np.array_equal(first, part.order())
+        assert np.array_equal(part.order(), plain.order())
+    assert np.array_equal(a["pos"], ref["pos"])
+    assert np.array_equal(a["vel"], ref["vel"])
+
+
 def test_native_rccl_world1_cell_exchange(nb, oracle):
     """The cell exchange through the library's own communicator (ncclAllReduce with MAX and SUM on the
     simulation's stream), world size 1: the same tree as the plain step (the keys carry one more
