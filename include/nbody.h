@@ -258,8 +258,8 @@ int nb_stage_ms(nb_sim *sim, float *out, int count);
  * rounding of a different summation order); it restores the speed of long runs: the direct-sum
  * kernel relies on neighbouring slots being neighbours in space, and the Barnes-Hut pipeline gathers
  * the state through its per-step sort, whose permutation drifts away from the identity as the bodies
- * mix.  nb_step and nb_step_distributed do it by themselves, every max(64, min(4096, 5e7 / n)) steps
- * for the direct sum and every 256 steps for Barnes-Hut (not while cells are exchanged: a rank then
+ * mix.  nb_step and nb_step_distributed do it by themselves, every max(32, min(4096, 1.4e11 / n^2))
+ * steps for the direct sum and every 256 steps for Barnes-Hut (not while cells are exchanged: a rank then
  * holds only its own bodies).  The reference keeps bodies in creation order and has nothing of the kind.
  * A partitioned simulation driven through nb_step_local / nb_step_finish may call it between
  * steps on EVERY rank, after all-gathering the velocity buffer the way the position buffer is

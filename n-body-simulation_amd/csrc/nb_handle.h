@@ -190,18 +190,21 @@ IntegrateArgs make_integrate_args(const S *s, int do_integrate)
 }
 
 // Steps between two renewals of the exchange order (device_refresh).  Direct sum: its run-against-wave
-// box tests rely on slot ranges being compact patches of space, and bodies wander; a renewal costs a
-// few passes over the per-body arrays, well below 1 % of the steps between at this interval.
+// box tests rely on slot ranges being compact patches of space, and bodies wander: at N = 65 536 the
+// spiral loses 18 % of its speed within 760 steps (4.72 -> 3.89 T interactions/s) and holds 4.7 when
+// the order is renewed every 50.  A renewal costs a few passes over the per-body arrays and some
+// twenty launches: every 32 steps where a step is long against that, less often for small systems,
+// whose steps are as short as the renewal (about 0.2 % of the time either way).
 // Barnes-Hut sorts every step anyway, but its leaf pass and the traversal's epilogue gather and
 // scatter the FP64 state through that sort's permutation, which drifts away from the identity as
 // the bodies mix (collision discs N = 5 M: 1.74 -> 1.65 ms/step at step 300, 2.21 -> 1.95 at step
-// 620 right after a renewal that takes 2.7 ms): every 256 steps.
+// 620 right after a renewal, which takes 0.9 ms): every 256 steps.
 inline long refresh_interval(int n, int alg)
 {
     if (alg != NB_ALG_DIRECT)
         return 256;
-    const long interval = 50000000L / (n > 0 ? n : 1);
-    return interval < 64 ? 64 : (interval > 4096 ? 4096 : interval);
+    const double interval = 1.4e11 / ((double)n * (double)n);
+    return interval < 32.0 ? 32 : (interval > 4096.0 ? 4096 : (long)interval);
 }
 
 template <class S>

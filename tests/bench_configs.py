@@ -162,6 +162,9 @@ if "d3" in which:
     run3(nb.DIRECT, nb.SPIRAL, 1000000, 3, 5.0e10, 1)
 if "d3c" in which:
     run3(nb.BARNES_HUT, nb.COLLISION, 5000000, 10, 2.0e10)
+if "c2long" in which:
+    for steps in (200, 1000, 3000):
+        run(nb.DIRECT, nb.SPIRAL, 65536, steps, 5)
 if "c2" in which:
     run(nb.DIRECT, nb.SPIRAL, 65536, 20)
 if "c3" in which:

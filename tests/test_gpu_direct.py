@@ -311,8 +311,8 @@ def test_refresh_order_changes_nothing_the_caller_sees(nb, alg):
 
 
 def test_long_direct_run_refreshes_by_itself(nb, oracle):
-    """n = 800000 bodies would refresh every 64 steps; here the interval is 4096, so force it
-    through a small n with many steps instead: 4200 steps of 64 bodies stay on the oracle's path."""
+    """A large system renews its order every 32 steps; for 64 bodies the interval is 4096, so many
+    steps of a small system it is: 4200 steps of 64 bodies stay on the oracle's path."""
     b0 = oracle.scenario(0, 64, 3)
     sim = nb.NBodySim(64, nb.DIRECT)
     sim.set_bodies(b0)
