@@ -386,6 +386,7 @@ int nb_step_cells(nb_sim *s, int phase)
     const BhStepArgs a = cells_args(s, 1);
     constexpr int EXCHANGE = 6;  // the caller's collectives run between the parts
     if (phase == 0) {
+        NB_TRY(pace_wait(s));
         mark(s, 0);
         NB_TRY(bh_cells_begin(s->stream, s->bh, a));
         mark(s, EXCHANGE);
@@ -407,6 +408,7 @@ int nb_step_cells(nb_sim *s, int phase)
         s->stepped = true;
         s->cells_steps += 1;
         NB_TRY(collect_timing(s));
+        NB_TRY(pace_mark(s));
     }
     s->cells_phase = (phase + 1) % 3;
     return NB_OK;

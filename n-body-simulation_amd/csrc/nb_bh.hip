@@ -86,6 +86,25 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const double2 *pos, int n,
 // of all ranks' bodies (minima negated so that one max-reduction serves), and the keys get
 // cells_levels digits whatever level closes the tree (cut[4]); a tree that closes deeper than that
 // cannot be exchanged at this level: *err is set.
+// First level whose cells no body ever opens in a tree over a box of width w0 and height h0 (32:
+// none): a cell is opened by a body that neither accepts it (dist <= width / theta) nor sees it
+// wholly inside its cutoff distance (dist >= collision_th - diagonal); when width / theta <
+// collision_th - diagonal no distance does both.  The margins (1e-4 each side) cover the float
+// rounding of the two thresholds the traversal compares.
+__device__ __forceinline__ uint32_t first_closed_level(double w0, double h0, double theta, double cth)
+{
+    uint32_t first_closed = 32u;
+    for (int l = BH_KEY_LEVELS; l >= 0; --l) {
+        const double w = ldexp(w0, -l), h = ldexp(h0, -l);
+        const double reach = cth * (1.0 - 1.0e-4) - sqrt(w * w + h * h);
+        if (reach > 0.0 && reach * (1.0 - 1.0e-4) > w / theta)
+            first_closed = (uint32_t)l;
+        else
+            break;  // cells only grow from here up
+    }
+    return first_closed;
+}
+
 constexpr int SORT_PACK_LEVELS = 15;        // key digits that leave bits 31..0 of the key word zero
 constexpr int SORT_PACK_MAX_N = 1 << 30;    // the index stays below bit 30, the lowest bit a sort pass with work reads
 constexpr uint32_t SORT_PACK_MASK = (1u << 30) - 1u;
@@ -139,23 +158,15 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         box[1] = (double)(float)(mxy + margin);  // topLeft.y
         box[2] = (double)(float)(mxx + margin);  // botRight.x
         box[3] = (double)(float)(mny - margin);  // botRight.y
-        // First level whose cells no body ever opens: a cell is opened by a body that neither
-        // accepts it (dist <= width / theta) nor sees it wholly inside its cutoff distance
-        // (dist >= collision_th - diagonal); when width / theta < collision_th - diagonal no
-        // distance does both.  What lies below such a cell is never looked at, so the tree is
-        // not built there and the keys stop at that level.  The margins (1e-4 each side) cover
-        // the float rounding of the two thresholds the traversal compares.
-        uint32_t first_closed = 32u;
+        // What lies below a cell that no body ever opens is never looked at, so the tree is not
+        // built there and the keys stop at that level.
+        uint32_t first_closed = 32u, ahead = 32u;
         if (bucket_depth == 0) {
             const double w0 = box[2] - box[0], h0 = box[1] - box[3];
-            for (int l = BH_KEY_LEVELS; l >= 0; --l) {
-                const double w = ldexp(w0, -l), h = ldexp(h0, -l);
-                const double reach = cth * (1.0 - 1.0e-4) - sqrt(w * w + h * h);
-                if (reach > 0.0 && reach * (1.0 - 1.0e-4) > w / theta)
-                    first_closed = (uint32_t)l;
-                else
-                    break;  // cells only grow from here up
-            }
+            first_closed = first_closed_level(w0, h0, theta, cth);
+            // what a box a tenth larger would need: the host sizes the coming steps' launches by it,
+            // so that it has switched before the box gets there (it runs a few steps ahead of the device)
+            ahead = first_closed_level(1.1 * w0, 1.1 * h0, theta, cth);
         }
         cut[0] = first_closed;
         cut[1] = bucket_depth > 0 ? (uint32_t)bucket_depth
@@ -182,8 +193,11 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         cut[7] = cut[2];
         if (cut[2] < (uint32_t)sort_first)
             cut[2] = (uint32_t)sort_first;
-        if (hint_host)
-            *hint_host = cut[4];  // host-visible: sizes the next steps' launches (a stale value only costs speed)
+        if (hint_host) {
+            // host-visible: sizes the next steps' launches (a stale value only costs speed)
+            const uint32_t soon = ahead < (uint32_t)BH_KEY_LEVELS ? ahead : (uint32_t)BH_KEY_LEVELS;
+            *hint_host = (cells_levels < 0 && bucket_depth == 0 && soon > cut[4]) ? soon : cut[4];
+        }
         if (hint_box) {           // host-visible: width and height of the box
             hint_box[0] = box[2] - box[0];
             hint_box[1] = box[1] - box[3];

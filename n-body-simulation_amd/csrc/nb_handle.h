@@ -69,7 +69,35 @@ struct SimCore {
 
     int collect_stats = 0;
     StageTimer timer;
+
+    // Barnes-Hut: the host sizes a step's launches by what the device reported about the steps
+    // before it; it may enqueue at most PACE_AHEAD steps beyond the last finished one, so that what
+    // it reads is never older than that (enough to keep the GPU fed: a step's launches take the
+    // host a small fraction of the step's time on the device).
+    static constexpr int PACE_AHEAD = 3, PACE_RING = 4;
+    hipEvent_t pace[PACE_RING] = {};
+    long paced = 0;  // steps whose end was marked
 };
+
+// Before the launches of a Barnes-Hut step: waits until at most PACE_AHEAD - 1 marked steps are unfinished.
+template <class S>
+int pace_wait(S *s)
+{
+    if (s->alg == NB_ALG_BARNES_HUT && s->paced >= S::PACE_AHEAD)
+        NB_HIP(hipEventSynchronize(s->pace[(s->paced - S::PACE_AHEAD) % S::PACE_RING]));
+    return NB_OK;
+}
+
+// After the launches of a Barnes-Hut step.
+template <class S>
+int pace_mark(S *s)
+{
+    if (s->alg == NB_ALG_BARNES_HUT) {
+        NB_HIP(hipEventRecord(s->pace[s->paced % S::PACE_RING], s->stream));
+        s->paced += 1;
+    }
+    return NB_OK;
+}
 
 template <class S>
 std::string fn(const char *name)
@@ -210,6 +238,7 @@ inline long refresh_interval(int n, int alg)
 template <class S>
 int step_local(S *s, int do_integrate)
 {
+    NB_TRY(pace_wait(s));
     return s->alg == NB_ALG_DIRECT ? s->direct_step(do_integrate) : s->bh_step(do_integrate);
 }
 
@@ -226,7 +255,7 @@ int step_finish(S *s)
         s->direct_flip();
         std::swap(s->pos, s->pos2);
     }
-    return NB_OK;
+    return pace_mark(s);
 }
 
 template <class S>
@@ -251,6 +280,11 @@ void release(S *s)
     comm_destroy(s->comm);
     s->comm = nullptr;
     s->timer.destroy();
+    for (auto &e : s->pace)
+        if (e) {
+            (void)hipEventDestroy(e);
+            e = nullptr;
+        }
     if (s->own_stream && s->stream)
         (void)hipStreamDestroy(s->stream);
 }
@@ -414,6 +448,9 @@ int api_create(const nb_params *params, int n, int alg, S **out)
     if (rc == NB_OK && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
         chk(fail(NB_ERR_HIP, "hipStreamCreate failed"));
     s->own_stream = rc == NB_OK;
+    for (auto &e : s->pace)
+        if (rc == NB_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+            chk(fail(NB_ERR_HIP, "hipEventCreate failed"));
     constexpr int D = S::D;
     chk(dev_alloc(s->pos, D * s->cap));
     chk(dev_alloc(s->vel, D * s->cap));
