@@ -192,9 +192,10 @@ int nb_step_distributed(nb_sim *sim, int nsteps);
  * (a collective call then) and returns only this rank's velocities up to date.  Needs a tree that
  * closes at level <= 10, Euler integration and bucket_depth 0; switch it on after nb_set_partition /
  * nb_comm_init and before the first step (nb_set_bodies goes back to NB_EXCHANGE_POSITIONS).
- * The level follows the bounding box: every 16 steps the host waits for the stream once and looks at
- * the box of the last step (the same on every rank).  A box that has grown so far that the tree
- * closes below level 10 SUSPENDS the cell exchange -- the ranks all-gather their positions once and
+ * The level follows the bounding box without the host waiting for the device: step t uses the box
+ * of step t - 4 (the same numbers on every rank, left by the device in pinned memory), enlarged by a
+ * tenth; a box that grows faster than that makes the next call fail with NB_ERR_OVERFLOW.  A box
+ * that has grown so far that the tree closes below level 10 SUSPENDS the cell exchange -- the ranks all-gather their positions once and
  * step by the position exchange -- until the box allows it again.
  * NB_EXCHANGE_AUTO: the same, and the cell exchange is also suspended while its records are more
  * data than the positions (twice 64 bytes x 4^level against 16 bytes x n).

@@ -108,6 +108,7 @@ int nb_sim::direct_step(int do_integrate)
 int nb_sim::bh_step(int do_integrate)
 {
     BhStepArgs a = bh_args(this, do_integrate);
+    bh.ring_step = (exchange != NB_EXCHANGE_POSITIONS && do_integrate) ? cells_steps : -1;
     timer.mark(stream, 0);
     NB_TRY(bh_bbox(stream, bh, a));
     timer.mark(stream, 1);
@@ -254,16 +255,24 @@ static BhStepArgs cells_args(nb_sim *s, int do_integrate)
     return a;
 }
 
-// Digits for the keys of the coming steps, from the box of the last finished step (the caller has
-// waited for the stream, so every rank reads the same box): the level at which a box half as large
-// again would close the tree, so that the box may grow for a while.  -1: the positions are the
-// better thing to exchange -- the tree closes below the dense pyramid's last level, or
-// (NB_EXCHANGE_AUTO) the cell records, which an all-reduce moves about twice, are more data than
-// the positions an all-gather moves once.
-static int choose_cells_levels(nb_sim *s)
+// The level of the exchanged cells follows the bounding box without the host ever waiting for the
+// device and without the ranks talking about it: the device leaves every step's box (the reduced
+// one, or while the cell exchange is suspended the box of all positions, which every rank holds --
+// the same numbers on every rank) in a pinned ring, and step t uses the box of step t - CELLS_LAG,
+// which has finished on every rank that enqueues step t (the host runs at most three steps ahead of
+// the device, pace_wait), enlarged by CELLS_MARGIN: the box may grow 2.4 % a step.  The first steps
+// use the box the bodies were set with.
+constexpr long CELLS_LAG = 4;
+constexpr double CELLS_MARGIN = 1.1;
+static_assert(CELLS_LAG < nb::BOX_RING && CELLS_LAG > nb_sim::PACE_AHEAD, "the slot read is written and not yet reused");
+
+// Digits for the keys of a step whose box is at most w x h: the level at which that box closes the
+// tree.  -1: the positions are the better thing to exchange -- the tree closes below the dense
+// pyramid's last level, or (NB_EXCHANGE_AUTO) the cell records, which an all-reduce moves about
+// twice, are more data than the positions an all-gather moves once.
+static int choose_cells_levels(nb_sim *s, double w, double h)
 {
-    const double w = ((volatile double *)s->bh.hint_box)[0], h = ((volatile double *)s->bh.hint_box)[1];
-    const int l = closed_level_for(1.5 * w, 1.5 * h, s->p.theta, s->p.collision_th);
+    const int l = closed_level_for(w, h, s->p.theta, s->p.collision_th);
     if (l > cells_max_level())
         return -1;
     if (s->exchange == NB_EXCHANGE_AUTO && 2 * cells_agg_doubles(l) * sizeof(double) > 2 * sizeof(double) * (size_t)s->n)
@@ -297,7 +306,10 @@ int nb_set_exchange(nb_sim *s, int mode)
     NB_HIP(hipStreamSynchronize(s->stream));
     const int before = s->exchange;
     s->exchange = mode;
-    const int levels = choose_cells_levels(s);
+    // (the box nb_set_bodies left: of all bodies, the same on every rank)
+    s->cells_box0[0] = ((volatile double *)s->bh.hint_box)[0];
+    s->cells_box0[1] = ((volatile double *)s->bh.hint_box)[1];
+    const int levels = choose_cells_levels(s, CELLS_MARGIN * s->cells_box0[0], CELLS_MARGIN * s->cells_box0[1]);
     if (levels < 0 && mode == NB_EXCHANGE_CELLS) {
         s->exchange = before;
         return fail(NB_ERR_OVERFLOW, "nb_set_exchange: with these parameters the tree closes below level " +
@@ -310,24 +322,27 @@ int nb_set_exchange(nb_sim *s, int mode)
     return NB_OK;
 }
 
-// Every 16 steps the host waits for the stream and looks at the box the device left: the level of
-// the exchanged cells follows it, and when the records of that level stop being the cheaper thing
-// to exchange (or the dense pyramid cannot hold the tree any more) the cell exchange is suspended
-// until they are again.  The decision is the same on every rank: the box is the reduced one, or,
-// while suspended, the box of all positions, which every rank holds.  *gather: the cell exchange
-// was suspended just now, so the ranks must all-gather their positions before the next step.
+// Before every step: the level for it (see CELLS_LAG above).  When the records of that level stop
+// being the cheaper thing to exchange, or the dense pyramid cannot hold the tree any more, the cell
+// exchange is suspended until they are again.  *gather: it was suspended just now, so the ranks
+// must all-gather their positions before the step.
 static int cells_housekeeping(nb_sim *s, bool *gather)
 {
     *gather = false;
-    if (s->exchange == NB_EXCHANGE_POSITIONS || s->cells_steps == 0 || s->cells_steps % 16 != 0 ||
-        s->cells_checked == s->cells_steps)
+    if (s->exchange == NB_EXCHANGE_POSITIONS || s->cells_checked == s->cells_steps)
         return NB_OK;
     s->cells_checked = s->cells_steps;
-    NB_HIP(hipStreamSynchronize(s->stream));
+    NB_TRY(pace_wait(s));  // the step CELLS_LAG back has finished: its box is in the ring
     if (s->cells_active && *(volatile uint32_t *)s->bh.err_host != 0u)
-        return fail(NB_ERR_OVERFLOW, "cell exchange: the bounding box grew by more than half within 16 steps; the last "
-                                     "steps' tree was cut above the level it closes at");
-    const int levels = choose_cells_levels(s);
+        return fail(NB_ERR_OVERFLOW, "cell exchange: the bounding box grew by more than a tenth within four steps; a "
+                                     "tree was cut above the level it closes at");
+    double w = s->cells_box0[0], h = s->cells_box0[1];
+    if (s->cells_steps >= CELLS_LAG) {
+        const volatile double *slot = s->bh.box_ring + 2 * ((s->cells_steps - CELLS_LAG) % BOX_RING);
+        w = slot[0];
+        h = slot[1];
+    }
+    const int levels = choose_cells_levels(s, CELLS_MARGIN * w, CELLS_MARGIN * h);
     if (levels < 0) {
         *gather = s->cells_active;
         s->cells_active = false;
@@ -391,6 +406,7 @@ int nb_step_cells(nb_sim *s, int phase)
         NB_TRY(bh_cells_begin(s->stream, s->bh, a));
         mark(s, EXCHANGE);
     } else if (phase == 1) {
+        s->bh.ring_step = s->cells_steps;
         mark(s, 1);
         NB_TRY(bh_cells_middle(s->stream, s->bh, a, s->cells_levels, 0));
         mark(s, 2);

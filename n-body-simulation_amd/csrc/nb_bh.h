@@ -16,6 +16,8 @@ constexpr int BH_KEY_LEVELS = 31;  // 2 bits per level in a 62-bit key
 constexpr int BH_MAX_DEPTH = 34;   // tree levels the build loops over (31 cell levels, leaves, spare)
 constexpr int BH_SCAN_BLOCKS = 1024;
 
+constexpr int BOX_RING = 8;
+
 struct BhBuffers {
     bool owned = false;  // the arrays were hipMalloc'ed by bh_alloc (bh_free releases them)
     int n = 0;
@@ -52,6 +54,8 @@ struct BhBuffers {
     uint32_t *levels_host = nullptr;  // pinned host word: tree levels of the last finished step
     uint32_t *hint_host = nullptr;    // pinned host word: level of the leaves of the last finished step's tree
     double *hint_box = nullptr;       // pinned host: width and height of the last finished step's bounding box
+    double *box_ring = nullptr;       // pinned host: the same by step, slot ring_step % BOX_RING (cell exchange: every
+    long ring_step = -1;              //   rank reads the box of ONE agreed earlier step); -1: not recorded
     uint32_t *err_host = nullptr;     // pinned host word: set when a cell-exchange step met a tree that closes
                                       // deeper than the level the cells were exchanged at
     int launched = 0;                 // levels the per-level build kernels were launched for

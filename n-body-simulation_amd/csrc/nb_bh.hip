@@ -112,7 +112,7 @@ constexpr uint32_t SORT_PACK_MASK = (1u << 30) - 1u;
 __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk, double margin, int bucket_depth,
                                                     double theta, double cth, double *box, uint32_t *cut, int pyr_levels,
                                                     uint32_t *hint_host, double *hint_box, int cells_levels, uint32_t *err,
-                                                    int n, int sort_first)
+                                                    int n, int sort_first, double *ring_slot)
 {
     double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
     for (int i = threadIdx.x; i < nblk; i += 256) {
@@ -202,6 +202,10 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
             hint_box[0] = box[2] - box[0];
             hint_box[1] = box[1] - box[3];
         }
+        if (ring_slot) {          // host-visible, by step: the same for the ranks that share this box
+            ring_slot[0] = box[2] - box[0];
+            ring_slot[1] = box[1] - box[3];
+        }
     }
 }
 
@@ -230,6 +234,12 @@ __global__ __launch_bounds__(256) void k_bbox_pack(const double *part, int nblk,
     }
 }
 
+// Where this step's box goes in the pinned ring (null: nobody asked, b.ring_step < 0).
+static double *box_ring_slot(const BhBuffers &b)
+{
+    return (b.box_ring && b.ring_step >= 0) ? b.box_ring + 2 * (b.ring_step % BOX_RING) : nullptr;
+}
+
 int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     int blocks = (a.n + 255) / 256;
@@ -251,7 +261,7 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     }
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, a.bucket_depth,
                        a.theta, a.collision_th, b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, -1, (uint32_t *)nullptr,
-                       a.n, b.sort_first);
+                       a.n, b.sort_first, box_ring_slot(b));
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
@@ -2631,7 +2641,7 @@ int bh_cells_middle(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_
         b.pyr_levels = PYR_MAX_LEVEL;
         b.sorted = 0;
         hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.red4, 1, a.bbox_margin, 0, a.theta, a.collision_th,
-                           b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, cells_levels, b.err_host, a.n, 0);
+                           b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, cells_levels, b.err_host, a.n, 0, box_ring_slot(b));
         NB_HIP(hipGetLastError());
         return a.n > 0 ? bh_keys(s, b, a) : (int)NB_OK;
     }
@@ -2714,8 +2724,9 @@ int bh_alloc(BhBuffers &b, int n)
     b.owned = true;
     NB_TRY(bh_layout(b, n, true, [](auto *&p, size_t count) { return dev_alloc(p, count); }));
     void *h = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(&h, 64 + sizeof(double) * 2 * BOX_RING, hipHostMallocDefault) != hipSuccess)
         return fail(NB_ERR_NOMEM, "hipHostMalloc failed");
+    b.box_ring = (double *)((char *)h + 64);
     b.levels_host = (uint32_t *)h;
     *b.levels_host = 0u;
     b.hint_host = b.levels_host + 1;

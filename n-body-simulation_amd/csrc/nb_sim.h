@@ -45,6 +45,7 @@ struct nb_sim : nb::SimCore<2> {
     bool cells_active = false; // cell exchange: in use for the coming steps (else suspended: positions are exchanged)
     long cells_steps = 0;      // cell exchange: steps since it was switched on
     long cells_checked = -1;   // cell exchange: the step count at which the level was last looked at
+    double cells_box0[2] = {0.0, 0.0};  // cell exchange: width and height of the box the bodies were set with
     int cells_phase = 0;       // cell exchange by hand: the next part of the step (0, 1, 2)
 
     bool static_fixed() const { return alg == NB_ALG_BARNES_HUT && p.bucket_depth > 0; }
