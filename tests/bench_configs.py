@@ -150,6 +150,9 @@ if "cells_long" in which:
     # cells must keep up with the box (an error from nb_step_cells otherwise)
     ranks(2, 5000000, 330, nb.EXCHANGE_CELLS)
     ranks(2, 5000000, 330, nb.EXCHANGE_AUTO)
+if "ranks8" in which:
+    ranks(8, 5000000, 5, nb.EXCHANGE_CELLS)
+    ranks(4, 5000000, 5, nb.EXCHANGE_CELLS)
 if "ranks" in which:
     for world in (2, 4, 8):
         ranks(world, 5000000, 5, nb.EXCHANGE_CELLS)
