@@ -333,14 +333,14 @@ static int cells_housekeeping(nb_sim *s, bool *gather)
         return NB_OK;
     s->cells_checked = s->cells_steps;
     NB_TRY(pace_wait(s));  // the step CELLS_LAG back has finished: its box is in the ring
-    if (s->cells_active && *(volatile uint32_t *)s->bh.err_host != 0u)
-        return fail(NB_ERR_OVERFLOW, "cell exchange: the bounding box grew by more than a tenth within four steps; a "
-                                     "tree was cut above the level it closes at");
     double w = s->cells_box0[0], h = s->cells_box0[1];
     if (s->cells_steps >= CELLS_LAG) {
-        const volatile double *slot = s->bh.box_ring + 2 * ((s->cells_steps - CELLS_LAG) % BOX_RING);
+        const volatile double *slot = s->bh.box_ring + BOX_SLOT * ((s->cells_steps - CELLS_LAG) % BOX_RING);
         w = slot[0];
         h = slot[1];
+        if (slot[2] != 0.0)  // (read from the slot, not from a flag of its own: every rank fails at the same step)
+            return fail(NB_ERR_OVERFLOW, "cell exchange: the bounding box grew by more than a tenth within four steps; "
+                                         "a tree was cut above the level it closes at");
     }
     const int levels = choose_cells_levels(s, CELLS_MARGIN * w, CELLS_MARGIN * h);
     if (levels < 0) {

@@ -16,7 +16,8 @@ constexpr int BH_KEY_LEVELS = 31;  // 2 bits per level in a 62-bit key
 constexpr int BH_MAX_DEPTH = 34;   // tree levels the build loops over (31 cell levels, leaves, spare)
 constexpr int BH_SCAN_BLOCKS = 1024;
 
-constexpr int BOX_RING = 8;
+constexpr int BOX_RING = 8;  // steps the pinned ring of boxes holds ...
+constexpr int BOX_SLOT = 4;  // ... in slots of {width, height, 1.0 if a cell-exchange tree was cut short, -}
 
 struct BhBuffers {
     bool owned = false;  // the arrays were hipMalloc'ed by bh_alloc (bh_free releases them)

@@ -205,6 +205,8 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         if (ring_slot) {          // host-visible, by step: the same for the ranks that share this box
             ring_slot[0] = box[2] - box[0];
             ring_slot[1] = box[1] - box[3];
+            // (every rank learns of a tree cut short at the same step, through the same slot)
+            ring_slot[2] = (cells_levels >= 0 && first_closed > (uint32_t)cells_levels) ? 1.0 : 0.0;
         }
     }
 }
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void k_bbox_pack(const double *part, int nblk,
 // Where this step's box goes in the pinned ring (null: nobody asked, b.ring_step < 0).
 static double *box_ring_slot(const BhBuffers &b)
 {
-    return (b.box_ring && b.ring_step >= 0) ? b.box_ring + 2 * (b.ring_step % BOX_RING) : nullptr;
+    return (b.box_ring && b.ring_step >= 0) ? b.box_ring + BOX_SLOT * (b.ring_step % BOX_RING) : nullptr;
 }
 
 int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
@@ -2724,7 +2726,7 @@ int bh_alloc(BhBuffers &b, int n)
     b.owned = true;
     NB_TRY(bh_layout(b, n, true, [](auto *&p, size_t count) { return dev_alloc(p, count); }));
     void *h = nullptr;
-    if (hipHostMalloc(&h, 64 + sizeof(double) * 2 * BOX_RING, hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(&h, 64 + sizeof(double) * BOX_SLOT * BOX_RING, hipHostMallocDefault) != hipSuccess)
         return fail(NB_ERR_NOMEM, "hipHostMalloc failed");
     b.box_ring = (double *)((char *)h + 64);
     b.levels_host = (uint32_t *)h;

@@ -298,6 +298,47 @@ def test_cell_exchange_is_suspended_when_the_box_outgrows_it(nb, oracle):
         assert np.linalg.norm(o["vel"][own] - ref["vel"][own], axis=1).max() <= 5.0  # speeds are 1e4..1e5 m/s
 
 
+def test_cell_exchange_reports_a_box_that_outgrows_its_margin(nb):
+    """The level of the exchanged cells allows the box to grow by a tenth within four steps.  A body
+    leaving ten times faster than that makes some step's tree close below the exchanged level: that
+    step's forces are not the reference's, and every rank is told so at the same later step."""
+    n, world = 3001, 2
+    b = nb.init_scenario(nb.SPIRAL, n, 23)
+    extent = np.abs(b["pos"]).max()
+    k = int(np.argmax(np.abs(b["pos"][:, 0])))
+    b["vel"][k] = (np.sign(b["pos"][k, 0]) * 1.5 * extent / nb.default_params().dt, 0.0)
+    hip = _hip()
+    ranks = [nb.NBodySim(n, nb.BARNES_HUT) for _ in range(world)]
+    failed_at = []
+    try:
+        for r, s in enumerate(ranks):
+            s.set_bodies(b)
+            s.set_partition(r, world)
+            s.set_exchange(nb.EXCHANGE_CELLS)
+        for step in range(12):
+            try:
+                said = [s.cells_level() for s in ranks]
+            except nb.NBodyError as e:
+                assert "grew by more than a tenth" in str(e)
+                # the other rank fails at the same step
+                for s in ranks[1:]:
+                    with pytest.raises(nb.NBodyError, match="grew by more than a tenth"):
+                        s.cells_level()
+                failed_at.append(step)
+                break
+            assert said[0] == said[1] and said[0][0] >= 0
+            for part, op in ((0, np.maximum), (1, np.add)):
+                for s in ranks:
+                    s.step_cells(part)
+                reduce_between_ranks(hip, ranks, part, op)
+            for s in ranks:
+                s.step_cells(2)
+    finally:
+        for s in ranks:
+            s.close()
+    assert failed_at and failed_at[0] <= 8, failed_at
+
+
 def test_auto_exchange_prefers_positions_for_a_small_system(nb):
     """NB_EXCHANGE_AUTO: 3000 positions are far less data than the records of 65 536 cells, so the
     cell exchange starts suspended; nb_step_cells refuses, nb_step_local works."""
