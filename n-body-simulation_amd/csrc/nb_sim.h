@@ -63,7 +63,7 @@ struct nb_sim : nb::SimCore<2> {
     void count_step()
     {
         if (exchange != NB_EXCHANGE_POSITIONS)
-            cells_steps += 1;  // (also while the cell exchange is suspended: its level is looked at every 16 steps)
+            cells_steps += 1;  // (also while the cell exchange is suspended: its level follows the box all the time)
     }
 };
 
