@@ -393,16 +393,19 @@ def main():
     alg_bytes = BH_FORCE_BYTES_PER_BODY * per_rank_bodies
     achieved = alg_bytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else 0.0
     traffic = None
+    l2_hit = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1:
         try:
-            traffic = json.load(open(tpath)).get("k_bh_force", {}).get("hbm_bytes_per_launch")
+            measured = json.load(open(tpath)).get("k_bh_force", {})
+            traffic = measured.get("hbm_bytes_per_launch")
+            l2_hit = measured.get("l2_hit_rate")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "k_bh_force", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": force_ms,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "l2_hit_rate": l2_hit, "kernel_ms": force_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "traffic_source": "profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of this kernel from separate "
+                "traffic_source": "profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE (and TCC hits / (hits + misses)) of this kernel from separate "
                                   "rocprofv3 --pmc passes over `bench.py --steps 2 --warmup 1` (steps 2-3 of this "
                                   "workload), not measured in this run"}
     if counters and force_ms > 0:
