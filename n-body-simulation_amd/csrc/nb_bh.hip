@@ -1155,13 +1155,35 @@ __device__ __forceinline__ void store_node(const ComArgs &a, uint32_t u, const u
     a.node_aux[u] = make_uint2((meta.z << 4) | ((1u << (meta.w & 0xffu)) - 1u), __float_as_uint(prune));
 }
 
+// A double moved between the lanes of a row of 16 by the VALU's data-parallel primitives (no trip
+// through the LDS crossbar as __shfl makes): CTRL 0x110 | k takes the value k lanes below in the
+// row; lanes without a source in their row get 0.
+template <int CTRL>
+__device__ __forceinline__ double row_move(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// The value one lane holds, for all lanes (the lane is the same for the whole wave).
+__device__ __forceinline__ double lane_value(double v, int l)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Sums over every run of bodies with one key (= every leaf with several bodies), left at the
 // run's first sorted position as {sum m x, sum m y, sum m, max radius}.  One wave per 64
 // consecutive sorted bodies: a segmented scan inside the wave gives the runs that end in its
 // chunk; of a run that crosses chunk boundaries every chunk leaves its part (the chunk where it
 // starts at the run's first position, the others in their own first slot) and k_leaf_finish adds
-// them up.  The order of the additions is fixed by the positions alone, so the sums are
-// reproducible.
+// them up.  The scan runs inside the rows of 16 lanes first (4 steps of row_move), then hands
+// the end of each row to the next (3 steps).  The order of the additions is fixed by the
+// positions alone, so the sums are reproducible.
 __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const uint32_t *idx, int n, const double2 *pos,
                                                    const double2 *mass_radius, double *leaf_sum, uint32_t *chunk_info,
                                                    const uint32_t *cut, uint2 *pc_range)
@@ -1186,67 +1208,76 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
     }
     const bool head = valid && (k == 0 || key != prev);
     const uint64_t heads = __builtin_amdgcn_ballot_w64(head);
+    // the run of the chunk's last body goes on in the next chunk?  (uniform)
+    const int tail = chunk + 64;
+    const uint64_t tail_key = tail < n ? keys[tail] : ~0ull;
+    // the next lane starts a run, or the sorted bodies end
+    const bool next_differs = lane == 63 ? tail_key != key : (((heads >> (lane + 1)) & 1ull) != 0ull || k + 1 >= n);
     if (cut[3] != 0u) {
         // Dense-pyramid build: a run of equal keys is the population of one cell of the level the
         // keys stop at; its first and one-past-last sorted positions go to that cell's slot (the
         // slots of empty cells were zeroed before this kernel).
         const int shift = 62 - 2 * (int)cut[1];
-        const uint64_t next = (uint64_t)__shfl_down((unsigned long long)key, 1);
-        const uint64_t after = lane == 63 ? ((chunk + 64 < n) ? keys[chunk + 64] : ~0ull) : next;
         const uint32_t cell = (uint32_t)(key >> shift);
         if (head)
             pc_range[cell].x = (uint32_t)k;
-        if (valid && (k + 1 >= n || after != key))
+        if (valid && next_differs)
             pc_range[cell].y = (uint32_t)k + 1u;
     }
-    // The bodies before the chunk's first head continue a run that started in an earlier chunk:
-    // their sums go to the chunk's first slot (no run starts there, so nothing else uses it), and
-    // k_leaf_finish adds them to that run.
+    // Segmented scan.  The bodies before the chunk's first head continue a run that started in an
+    // earlier chunk; for the scan they are a run of their own that starts at lane 0.
     const int first_head = heads ? (int)__builtin_ctzll(heads) : 64;
-    if (first_head > 0) {
-        const bool in_head = valid && lane < first_head;
-        double hm = in_head ? sm : 0.0, hx = in_head ? sx : 0.0, hy = in_head ? sy : 0.0, hr = in_head ? rm : 0.0;
+    const uint64_t upto = (heads | 1ull) & ((2ull << lane) - 1ull);
+    const int start = 63 - __builtin_clzll(upto);  // first lane of this lane's run
+    const int dist = lane - start;
+    const int in_row = dist < (lane & 15) ? dist : (lane & 15);
+#define NB_ROW_STEP(O)                                                                                        \
+    {                                                                                                         \
+        const double tm = row_move<0x110 | O>(sm), tx = row_move<0x110 | O>(sx), ty = row_move<0x110 | O>(sy), \
+                     tr = row_move<0x110 | O>(rm);                                                            \
+        if (O <= in_row) {                                                                                    \
+            sm += tm;                                                                                         \
+            sx += tx;                                                                                         \
+            sy += ty;                                                                                         \
+            rm = fmax(rm, tr);                                                                                \
+        }                                                                                                     \
+    }
+    NB_ROW_STEP(1)
+    NB_ROW_STEP(2)
+    NB_ROW_STEP(4)
+    NB_ROW_STEP(8)
+#undef NB_ROW_STEP
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            hm += __shfl_xor(hm, o);
-            hx += __shfl_xor(hx, o);
-            hy += __shfl_xor(hy, o);
-            hr = fmax(hr, __shfl_xor(hr, o));
+    for (int r = 1; r < 4; ++r) {
+        // the end of row r - 1 is complete by now; the lanes of row r whose run began before the row take it
+        const double em = lane_value(sm, 16 * r - 1), ex = lane_value(sx, 16 * r - 1), ey = lane_value(sy, 16 * r - 1),
+                     er = lane_value(rm, 16 * r - 1);
+        if ((lane >> 4) == r && start < 16 * r) {
+            sm = em + sm;
+            sx = ex + sx;
+            sy = ey + sy;
+            rm = fmax(er, rm);
         }
-        if (lane == 0) {
-            double *o = leaf_sum + 4 * (size_t)chunk;
-            o[0] = hx;
-            o[1] = hy;
-            o[2] = hm;
-            o[3] = hr;
-        }
+    }
+    // The part of the earlier run goes to the chunk's first slot (no run starts there, so nothing
+    // else uses it), and k_leaf_finish adds it to that run.
+    if (first_head > 0 && lane == first_head - 1) {
+        double *o = leaf_sum + 4 * (size_t)chunk;
+        o[0] = sx;
+        o[1] = sy;
+        o[2] = sm;
+        o[3] = rm;
     }
     if (heads == 0ull) {
         if (lane == 0)
             chunk_info[chunk >> 6] = 64u | (LEAF_NO_OWNER << 8);
         return;  // the whole chunk lies inside a run that started earlier
     }
-    // first lane of this lane's run, if the run starts in this chunk
-    const uint64_t upto = heads & ((2ull << lane) - 1ull);
-    const int start = upto ? 63 - __builtin_clzll(upto) : -1;
-    const int dist = start >= 0 ? lane - start : 0;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double tm = __shfl_up(sm, o), tx = __shfl_up(sx, o), ty = __shfl_up(sy, o), tr = __shfl_up(rm, o);
-        if (o <= dist) {
-            sm += tm;
-            sx += tx;
-            sy += ty;
-            rm = fmax(rm, tr);
-        }
-    }
-    // last lane of each run inside the chunk: the next lane starts a run, or the chunk ends
+    // last lane of each run that starts inside the chunk: the next lane starts a run, or the chunk ends
     const bool last_in_chunk = lane == 63 || !valid || ((heads >> (lane + 1)) & 1ull) || k + 1 >= n;
-    const bool ends = valid && start >= 0 && last_in_chunk;
-    // does the run of the chunk's last body go on in the next chunk?
-    const int tail = chunk + 64;
-    const uint64_t last_key = (uint64_t)__shfl(key, 63);
-    const bool goes_on = tail < n && keys[tail] == last_key;  // uniform
+    const bool ends = valid && lane >= first_head && last_in_chunk;
+    const bool goes_on = tail < n && tail_key == (uint64_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 63) +
+                                                     ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 63) << 32);
     if (ends && !(lane == 63 && goes_on) && dist > 0) {
         double *o = leaf_sum + 4 * (size_t)(chunk + start);
         o[0] = sx;
@@ -1256,8 +1287,8 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
     }
     // The run of the chunk's last body, when it started here and goes on: its part inside the
     // chunk is left at its start, and k_leaf_finish adds the parts of the chunks it crosses.
-    const int start63 = __shfl(start, 63);
-    const bool owner = goes_on && start63 >= 0;
+    const int start63 = 63 - __builtin_clzll(heads);
+    const bool owner = goes_on;
     if (owner && lane == 63) {
         double *o = leaf_sum + 4 * (size_t)(chunk + start63);
         o[0] = sx;
