@@ -1155,35 +1155,13 @@ __device__ __forceinline__ void store_node(const ComArgs &a, uint32_t u, const u
     a.node_aux[u] = make_uint2((meta.z << 4) | ((1u << (meta.w & 0xffu)) - 1u), __float_as_uint(prune));
 }
 
-// A double moved between the lanes of a row of 16 by the VALU's data-parallel primitives (no trip
-// through the LDS crossbar as __shfl makes): CTRL 0x110 | k takes the value k lanes below in the
-// row; lanes without a source in their row get 0.
-template <int CTRL>
-__device__ __forceinline__ double row_move(double v)
-{
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// The value one lane holds, for all lanes (the lane is the same for the whole wave).
-__device__ __forceinline__ double lane_value(double v, int l)
-{
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 // Sums over every run of bodies with one key (= every leaf with several bodies), left at the
 // run's first sorted position as {sum m x, sum m y, sum m, max radius}.  One wave per 64
 // consecutive sorted bodies: a segmented scan inside the wave gives the runs that end in its
 // chunk; of a run that crosses chunk boundaries every chunk leaves its part (the chunk where it
 // starts at the run's first position, the others in their own first slot) and k_leaf_finish adds
-// them up.  The scan runs inside the rows of 16 lanes first (4 steps of row_move), then hands
-// the end of each row to the next (3 steps).  The order of the additions is fixed by the
-// positions alone, so the sums are reproducible.
+// them up.  The order of the additions is fixed by the positions alone (wave_run_scan), so the
+// sums are reproducible.
 __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const uint32_t *idx, int n, const double2 *pos,
                                                    const double2 *mass_radius, double *leaf_sum, uint32_t *chunk_info,
                                                    const uint32_t *cut, uint2 *pc_range)
@@ -1230,34 +1208,12 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
     const uint64_t upto = (heads | 1ull) & ((2ull << lane) - 1ull);
     const int start = 63 - __builtin_clzll(upto);  // first lane of this lane's run
     const int dist = lane - start;
-    const int in_row = dist < (lane & 15) ? dist : (lane & 15);
-#define NB_ROW_STEP(O)                                                                                        \
-    {                                                                                                         \
-        const double tm = row_move<0x110 | O>(sm), tx = row_move<0x110 | O>(sx), ty = row_move<0x110 | O>(sy), \
-                     tr = row_move<0x110 | O>(rm);                                                            \
-        if (O <= in_row) {                                                                                    \
-            sm += tm;                                                                                         \
-            sx += tx;                                                                                         \
-            sy += ty;                                                                                         \
-            rm = fmax(rm, tr);                                                                                \
-        }                                                                                                     \
-    }
-    NB_ROW_STEP(1)
-    NB_ROW_STEP(2)
-    NB_ROW_STEP(4)
-    NB_ROW_STEP(8)
-#undef NB_ROW_STEP
-#pragma unroll
-    for (int r = 1; r < 4; ++r) {
-        // the end of row r - 1 is complete by now; the lanes of row r whose run began before the row take it
-        const double em = lane_value(sm, 16 * r - 1), ex = lane_value(sx, 16 * r - 1), ey = lane_value(sy, 16 * r - 1),
-                     er = lane_value(rm, 16 * r - 1);
-        if ((lane >> 4) == r && start < 16 * r) {
-            sm = em + sm;
-            sx = ex + sx;
-            sy = ey + sy;
-            rm = fmax(er, rm);
-        }
+    {
+        double sums[3] = {sm, sx, sy};
+        wave_run_scan<3>(sums, rm, lane, start);
+        sm = sums[0];
+        sx = sums[1];
+        sy = sums[2];
     }
     // The part of the earlier run goes to the chunk's first slot (no run starts there, so nothing
     // else uses it), and k_leaf_finish adds it to that run.
@@ -1276,8 +1232,7 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const uint64_t *keys, const u
     // last lane of each run that starts inside the chunk: the next lane starts a run, or the chunk ends
     const bool last_in_chunk = lane == 63 || !valid || ((heads >> (lane + 1)) & 1ull) || k + 1 >= n;
     const bool ends = valid && lane >= first_head && last_in_chunk;
-    const bool goes_on = tail < n && tail_key == (uint64_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 63) +
-                                                     ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 63) << 32);
+    const bool goes_on = tail < n && tail_key == lane_value(key, 63);
     if (ends && !(lane == 63 && goes_on) && dist > 0) {
         double *o = leaf_sum + 4 * (size_t)(chunk + start);
         o[0] = sx;

@@ -283,55 +283,39 @@ __global__ __launch_bounds__(256) void k_leaf_sums3(const uint64_t *keys, const 
         rad_s[k] = (float)(rm * inv_len);
     }
     const uint64_t heads = __builtin_amdgcn_ballot_w64(valid && (k == 0 || key != prev));
-    // the bodies before the chunk's first head continue a run from an earlier chunk: their sums
-    // go to the chunk's first slot (no run starts there) for leaf_finish to add to that run
+    // Segmented scan.  The bodies before the chunk's first head continue a run from an earlier
+    // chunk; for the scan they are a run of their own that starts at lane 0.
     const int first_head = heads ? (int)__builtin_ctzll(heads) : 64;
-    if (first_head > 0) {
-        const bool in_head = valid && lane < first_head;
-        double hm = in_head ? sm : 0.0, hx = in_head ? sx : 0.0, hy = in_head ? sy : 0.0, hz = in_head ? sz : 0.0,
-               hr = in_head ? rm : 0.0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            hm += __shfl_xor(hm, o);
-            hx += __shfl_xor(hx, o);
-            hy += __shfl_xor(hy, o);
-            hz += __shfl_xor(hz, o);
-            hr = fmax(hr, __shfl_xor(hr, o));
-        }
-        if (lane == 0) {
-            double *o = leaf_sum + 6 * (size_t)chunk;
-            o[0] = hx;
-            o[1] = hy;
-            o[2] = hz;
-            o[3] = hm;
-            o[4] = hr;
-        }
+    const uint64_t upto = (heads | 1ull) & ((2ull << lane) - 1ull);
+    const int start = 63 - __builtin_clzll(upto);  // first lane of this lane's run
+    const int dist = lane - start;
+    {
+        double sums[4] = {sm, sx, sy, sz};
+        wave_run_scan<4>(sums, rm, lane, start);
+        sm = sums[0];
+        sx = sums[1];
+        sy = sums[2];
+        sz = sums[3];
+    }
+    // the part of the earlier run goes to the chunk's first slot (no run starts there) for
+    // leaf_finish to add to that run
+    if (first_head > 0 && lane == first_head - 1) {
+        double *o = leaf_sum + 6 * (size_t)chunk;
+        o[0] = sx;
+        o[1] = sy;
+        o[2] = sz;
+        o[3] = sm;
+        o[4] = rm;
     }
     if (heads == 0ull) {
         if (lane == 0)
             chunk_info[chunk >> 6] = 64u | (LEAF_NO_OWNER << 8);
         return;  // the whole chunk lies inside a run that started earlier
     }
-    const uint64_t upto = heads & ((2ull << lane) - 1ull);
-    const int start = upto ? 63 - __builtin_clzll(upto) : -1;
-    const int dist = start >= 0 ? lane - start : 0;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double tm = __shfl_up(sm, o), tx = __shfl_up(sx, o), ty = __shfl_up(sy, o), tz = __shfl_up(sz, o),
-                     tr = __shfl_up(rm, o);
-        if (o <= dist) {
-            sm += tm;
-            sx += tx;
-            sy += ty;
-            sz += tz;
-            rm = fmax(rm, tr);
-        }
-    }
     const bool last_in_chunk = lane == 63 || !valid || ((heads >> (lane + 1)) & 1ull) || k + 1 >= n;
-    const bool ends = valid && start >= 0 && last_in_chunk;
+    const bool ends = valid && lane >= first_head && last_in_chunk;
     const int tail = chunk + 64;
-    const uint64_t last_key = (uint64_t)__shfl(key, 63);
-    const bool goes_on = tail < n && keys[tail] == last_key;  // uniform
+    const bool goes_on = tail < n && keys[tail] == lane_value(key, 63);  // uniform
     if (ends && !(lane == 63 && goes_on) && dist > 0) {
         double *o = leaf_sum + 6 * (size_t)(chunk + start);
         o[0] = sx;
@@ -342,8 +326,8 @@ __global__ __launch_bounds__(256) void k_leaf_sums3(const uint64_t *keys, const 
     }
     // the run of the chunk's last body, when it started here and goes on: its part inside the
     // chunk stays at its start, leaf_finish adds the parts of the chunks it crosses
-    const int start63 = __shfl(start, 63);
-    const bool owner = goes_on && start63 >= 0;
+    const int start63 = 63 - __builtin_clzll(heads);
+    const bool owner = goes_on;
     if (owner && lane == 63) {
         double *o = leaf_sum + 6 * (size_t)(chunk + start63);
         o[0] = sx;

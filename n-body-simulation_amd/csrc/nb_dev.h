@@ -49,6 +49,76 @@ static __device__ __forceinline__ int block_sum_256(int v)
     return wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3];
 }
 
+// A double moved between the lanes of a row of 16 by the VALU's data-parallel primitives (no trip
+// through the LDS crossbar as __shfl makes): CTRL 0x110 | k takes the value k lanes below in the
+// row; lanes without a source in their row get 0.
+template <int CTRL>
+static __device__ __forceinline__ double row_move(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// The value one lane holds, for all lanes (the lane is the same for the whole wave).
+static __device__ __forceinline__ double lane_value(double v, int l)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+static __device__ __forceinline__ uint64_t lane_value(uint64_t v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Inclusive scan over the runs of a wave: on return lane l holds the sums of s[] and the maximum of
+// m over the lanes start .. l, where start (<= l) is the first lane of l's run.  All 64 lanes must be
+// active.  The scan runs inside the rows of 16 lanes first (4 steps of row_move), then hands the
+// end of each row to the next (3 steps).  The order of the additions depends on the lane numbers
+// alone.
+template <int NSUM>
+static __device__ __forceinline__ void wave_run_scan(double (&s)[NSUM], double &m, int lane, int start)
+{
+    const int dist = lane - start;
+    const int in_row = dist < (lane & 15) ? dist : (lane & 15);
+#define NB_ROW_STEP(O)                             \
+    {                                              \
+        double t[NSUM];                            \
+        _Pragma("unroll") for (int v = 0; v < NSUM; ++v) t[v] = row_move<0x110 | O>(s[v]); \
+        const double tm = row_move<0x110 | O>(m);  \
+        if (O <= in_row) {                         \
+            _Pragma("unroll") for (int v = 0; v < NSUM; ++v) s[v] += t[v]; \
+            m = fmax(m, tm);                       \
+        }                                          \
+    }
+    NB_ROW_STEP(1)
+    NB_ROW_STEP(2)
+    NB_ROW_STEP(4)
+    NB_ROW_STEP(8)
+#undef NB_ROW_STEP
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        // the end of row r - 1 is complete by now; the lanes of row r whose run began before the row take it
+        double e[NSUM];
+#pragma unroll
+        for (int v = 0; v < NSUM; ++v)
+            e[v] = lane_value(s[v], 16 * r - 1);
+        const double em = lane_value(m, 16 * r - 1);
+        if ((lane >> 4) == r && start < 16 * r) {
+#pragma unroll
+            for (int v = 0; v < NSUM; ++v)
+                s[v] = e[v] + s[v];
+            m = fmax(em, m);
+        }
+    }
+}
+
 // chunk_info word of the leaf pass (per 64 sorted bodies): first lane that starts a run of equal
 // keys (64: none) | lane where the run that goes on into the next chunk starts << 8, or:
 constexpr unsigned LEAF_NO_OWNER = 0xffu;  // no run of this chunk goes on into the next
