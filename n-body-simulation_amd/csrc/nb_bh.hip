@@ -91,18 +91,19 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const double2 *pos, int n,
 // wholly inside its cutoff distance (dist >= collision_th - diagonal); when width / theta <
 // collision_th - diagonal no distance does both.  The margins (1e-4 each side) cover the float
 // rounding of the two thresholds the traversal compares.
+// One level a lane: lane l and lane 32 + l test level l, and the two halves of the wave may be given
+// different boxes.  All 64 lanes must be active; every lane returns the answer of its half.
 __device__ __forceinline__ uint32_t first_closed_level(double w0, double h0, double theta, double cth)
 {
-    uint32_t first_closed = 32u;
-    for (int l = BH_KEY_LEVELS; l >= 0; --l) {
-        const double w = ldexp(w0, -l), h = ldexp(h0, -l);
-        const double reach = cth * (1.0 - 1.0e-4) - sqrt(w * w + h * h);
-        if (reach > 0.0 && reach * (1.0 - 1.0e-4) > w / theta)
-            first_closed = (uint32_t)l;
-        else
-            break;  // cells only grow from here up
-    }
-    return first_closed;
+    static_assert(BH_KEY_LEVELS == 31, "one lane per level, 32 levels");
+    const int lane = lane_id(), l = lane & 31;
+    const double w = ldexp(w0, -l), h = ldexp(h0, -l);
+    const double reach = cth * (1.0 - 1.0e-4) - sqrt(w * w + h * h);
+    const bool closed = reach > 0.0 && reach * (1.0 - 1.0e-4) > w / theta;
+    // cells only grow towards the root: the answer is the level above the deepest one that fails
+    const uint64_t both = __builtin_amdgcn_ballot_w64(!closed);
+    const uint32_t fails = lane < 32 ? (uint32_t)both : (uint32_t)(both >> 32);
+    return fails ? 32u - (uint32_t)__builtin_clz(fails) : 0u;
 }
 
 constexpr int SORT_PACK_LEVELS = 15;        // key digits that leave bits 31..0 of the key word zero
@@ -137,77 +138,92 @@ __global__ __launch_bounds__(256) void k_bbox_final(const double *part, int nblk
         sh[w][3] = mxy;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) {
-            mnx = fmin(mnx, sh[k][0]);
-            mxx = fmax(mxx, sh[k][1]);
-            mny = fmin(mny, sh[k][2]);
-            mxy = fmax(mxy, sh[k][3]);
-        }
-        // fminf/fmaxf of the reference round every candidate to float (barnesHut.cpp:28-31);
-        // rounding is monotone, so rounding the extreme gives the same box.
-        if (bucket_depth > 0) {
-            // the GPU program reduces the positions through fminf/fmaxf first and pads afterwards
-            // (barnesHut_kernel.cu:94-108): two roundings per bound
-            mnx = (double)(float)mnx;
-            mxx = (double)(float)mxx;
-            mny = (double)(float)mny;
-            mxy = (double)(float)mxy;
-        }
-        box[0] = (double)(float)(mnx - margin);  // topLeft.x
-        box[1] = (double)(float)(mxy + margin);  // topLeft.y
-        box[2] = (double)(float)(mxx + margin);  // botRight.x
-        box[3] = (double)(float)(mny - margin);  // botRight.y
-        // What lies below a cell that no body ever opens is never looked at, so the tree is not
-        // built there and the keys stop at that level.
-        uint32_t first_closed = 32u, ahead = 32u;
-        if (bucket_depth == 0) {
-            const double w0 = box[2] - box[0], h0 = box[1] - box[3];
-            first_closed = first_closed_level(w0, h0, theta, cth);
-            // what a box a tenth larger would need: the host sizes the coming steps' launches by it,
-            // so that it has switched before the box gets there (it runs a few steps ahead of the device)
-            ahead = first_closed_level(1.1 * w0, 1.1 * h0, theta, cth);
-        }
-        cut[0] = first_closed;
-        cut[1] = bucket_depth > 0 ? (uint32_t)bucket_depth
-                                  : (first_closed < (uint32_t)BH_KEY_LEVELS ? first_closed : (uint32_t)BH_KEY_LEVELS);
-        cut[2] = (uint32_t)sort_first_pass(2 * (int)cut[1]);
-        // The dense-pyramid build runs when the host launched its kernels (pyr_levels >= 0) and
-        // the keys stop at a level it covers; otherwise the level-by-level build does the step.
-        cut[3] = (pyr_levels >= 0 && (int)cut[1] <= pyr_levels) ? 1u : 0u;
-        cut[4] = cut[1];  // the level of the tree's leaves
-        if (cells_levels >= 0) {
-            cut[1] = (uint32_t)cells_levels;
-            cut[2] = (uint32_t)sort_first_pass(2 * cells_levels);
-            cut[3] = 1u;
-            cut[4] = first_closed <= (uint32_t)cells_levels ? first_closed : (uint32_t)cells_levels;
-            if (first_closed > (uint32_t)cells_levels && err)
-                *err = 1u;
-        }
-        // Keys of at most 15 digits leave the low 32 bits of the key word free: the body's index (below 2^30)
-        // travels there through the sort instead of in an array of its own (see k_sort_scatter).
-        cut[5] = (cut[1] <= (uint32_t)SORT_PACK_LEVELS && n <= SORT_PACK_MAX_N) ? 1u : 0u;
-        // The host launches the sort's passes from sort_first on (it sizes them by the keys of the
-        // last step it knows): cut[2] becomes the first pass that RUNS, cut[7] keeps the first the
-        // keys NEED; if that is lower, k_sort_fix finishes the order.
-        cut[7] = cut[2];
-        if (cut[2] < (uint32_t)sort_first)
-            cut[2] = (uint32_t)sort_first;
-        if (hint_host) {
-            // host-visible: sizes the next steps' launches (a stale value only costs speed)
-            const uint32_t soon = ahead < (uint32_t)BH_KEY_LEVELS ? ahead : (uint32_t)BH_KEY_LEVELS;
-            *hint_host = (cells_levels < 0 && bucket_depth == 0 && soon > cut[4]) ? soon : cut[4];
-        }
-        if (hint_box) {           // host-visible: width and height of the box
-            hint_box[0] = box[2] - box[0];
-            hint_box[1] = box[1] - box[3];
-        }
-        if (ring_slot) {          // host-visible, by step: the same for the ranks that share this box
-            ring_slot[0] = box[2] - box[0];
-            ring_slot[1] = box[1] - box[3];
-            // (every rank learns of a tree cut short at the same step, through the same slot)
-            ring_slot[2] = (cells_levels >= 0 && first_closed > (uint32_t)cells_levels) ? 1.0 : 0.0;
-        }
+    if (threadIdx.x >= 64)
+        return;
+    // The first wave goes on, every lane with the same box: the level tests below run one level a
+    // lane (one lane walking down the levels spent 10 us of every step here); lane 0 writes.
+    const bool writer = threadIdx.x == 0;
+    mnx = sh[0][0];
+    mxx = sh[0][1];
+    mny = sh[0][2];
+    mxy = sh[0][3];
+    for (int k = 1; k < 4; ++k) {
+        mnx = fmin(mnx, sh[k][0]);
+        mxx = fmax(mxx, sh[k][1]);
+        mny = fmin(mny, sh[k][2]);
+        mxy = fmax(mxy, sh[k][3]);
+    }
+    // fminf/fmaxf of the reference round every candidate to float (barnesHut.cpp:28-31);
+    // rounding is monotone, so rounding the extreme gives the same box.
+    if (bucket_depth > 0) {
+        // the GPU program reduces the positions through fminf/fmaxf first and pads afterwards
+        // (barnesHut_kernel.cu:94-108): two roundings per bound
+        mnx = (double)(float)mnx;
+        mxx = (double)(float)mxx;
+        mny = (double)(float)mny;
+        mxy = (double)(float)mxy;
+    }
+    const double tlx = (double)(float)(mnx - margin), tly = (double)(float)(mxy + margin);
+    const double brx = (double)(float)(mxx + margin), bry = (double)(float)(mny - margin);
+    // What lies below a cell that no body ever opens is never looked at, so the tree is not
+    // built there and the keys stop at that level.
+    uint32_t first_closed = 32u, ahead = 32u;
+    if (bucket_depth == 0) {
+        // the upper half of the wave answers for a box a tenth larger: the host sizes the coming
+        // steps' launches by that, so that it has switched before the box gets there (it runs a few
+        // steps ahead of the device)
+        const double grow = lane_id() < 32 ? 1.0 : 1.1;
+        const uint32_t level = first_closed_level(grow * (brx - tlx), grow * (tly - bry), theta, cth);
+        first_closed = (uint32_t)__builtin_amdgcn_readlane((int)level, 0);
+        ahead = (uint32_t)__builtin_amdgcn_readlane((int)level, 32);
+    }
+    if (!writer)
+        return;
+    box[0] = tlx;  // topLeft.x
+    box[1] = tly;  // topLeft.y
+    box[2] = brx;  // botRight.x
+    box[3] = bry;  // botRight.y
+    cut[0] = first_closed;
+    uint32_t key_levels = bucket_depth > 0 ? (uint32_t)bucket_depth
+                                           : (first_closed < (uint32_t)BH_KEY_LEVELS ? first_closed : (uint32_t)BH_KEY_LEVELS);
+    uint32_t first_pass = (uint32_t)sort_first_pass(2 * (int)key_levels);
+    // The dense-pyramid build runs when the host launched its kernels (pyr_levels >= 0) and
+    // the keys stop at a level it covers; otherwise the level-by-level build does the step.
+    uint32_t pyramid = (pyr_levels >= 0 && (int)key_levels <= pyr_levels) ? 1u : 0u;
+    uint32_t leaf_level = key_levels;  // the level of the tree's leaves
+    if (cells_levels >= 0) {
+        key_levels = (uint32_t)cells_levels;
+        first_pass = (uint32_t)sort_first_pass(2 * cells_levels);
+        pyramid = 1u;
+        leaf_level = first_closed <= (uint32_t)cells_levels ? first_closed : (uint32_t)cells_levels;
+        if (first_closed > (uint32_t)cells_levels && err)
+            *err = 1u;
+    }
+    cut[1] = key_levels;
+    cut[3] = pyramid;
+    cut[4] = leaf_level;
+    // Keys of at most 15 digits leave the low 32 bits of the key word free: the body's index (below 2^30)
+    // travels there through the sort instead of in an array of its own (see k_sort_scatter).
+    cut[5] = (key_levels <= (uint32_t)SORT_PACK_LEVELS && n <= SORT_PACK_MAX_N) ? 1u : 0u;
+    // The host launches the sort's passes from sort_first on (it sizes them by the keys of the
+    // last step it knows): cut[2] becomes the first pass that RUNS, cut[7] keeps the first the
+    // keys NEED; if that is lower, k_sort_fix finishes the order.
+    cut[7] = first_pass;
+    cut[2] = first_pass < (uint32_t)sort_first ? (uint32_t)sort_first : first_pass;
+    if (hint_host) {
+        // host-visible: sizes the next steps' launches (a stale value only costs speed)
+        const uint32_t soon = ahead < (uint32_t)BH_KEY_LEVELS ? ahead : (uint32_t)BH_KEY_LEVELS;
+        *hint_host = (cells_levels < 0 && bucket_depth == 0 && soon > leaf_level) ? soon : leaf_level;
+    }
+    if (hint_box) {           // host-visible: width and height of the box
+        hint_box[0] = brx - tlx;
+        hint_box[1] = tly - bry;
+    }
+    if (ring_slot) {          // host-visible, by step: the same for the ranks that share this box
+        ring_slot[0] = brx - tlx;
+        ring_slot[1] = tly - bry;
+        // (every rank learns of a tree cut short at the same step, through the same slot)
+        ring_slot[2] = (cells_levels >= 0 && first_closed > (uint32_t)cells_levels) ? 1.0 : 0.0;
     }
 }
 
@@ -622,37 +638,41 @@ __global__ __launch_bounds__(256) void k_sort_fix(uint64_t *keys, uint32_t *idx,
 {
     if (cut[7] >= cut[2])
         return;  // every pass the keys need was launched
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n)
-        return;
     const int shift = (int)cut[2] * SORT_BITS - 2;  // the launched passes ordered key bits [shift, 62)
-    const uint64_t pre = keys[i] >> shift;
-    // (a neighbouring run's thread may be moving its pairs meanwhile: they keep their upper bits)
-    if (i > 0 && (keys[i - 1] >> shift) == pre)
-        return;  // not the first pair of a run
-    int end = i + 1;
-    while (end < n && (keys[end] >> shift) == pre)
-        ++end;
-    for (int a = i + 1; a < end; ++a) {
-        const uint64_t ka = keys[a];
-        const uint32_t va = idx[a];
-        int at = a;
-        while (at > i && keys[at - 1] > ka) {
-            keys[at] = keys[at - 1];
-            idx[at] = idx[at - 1];
-            --at;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint64_t pre = keys[i] >> shift;
+        // (a neighbouring run's thread may be moving its pairs meanwhile: they keep their upper bits)
+        if (i > 0 && (keys[i - 1] >> shift) == pre)
+            continue;  // not the first pair of a run
+        int end = i + 1;
+        while (end < n && (keys[end] >> shift) == pre)
+            ++end;
+        for (int a = i + 1; a < end; ++a) {
+            const uint64_t ka = keys[a];
+            const uint32_t va = idx[a];
+            int at = a;
+            while (at > i && keys[at - 1] > ka) {
+                keys[at] = keys[at - 1];
+                idx[at] = idx[at - 1];
+                --at;
+            }
+            keys[at] = ka;
+            idx[at] = va;
         }
-        keys[at] = ka;
-        idx[at] = va;
     }
 }
+
+// The repair is almost never needed: a small grid keeps the launch that finds that out short.
+constexpr int SORT_FIX_BLOCKS = 2048;
 
 int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 {
     b.sorted = 0;
     NB_TRY(sort_pairs(s, b.keys, b.idx, a.n, b.cut, b.hist, b.hist_totals, b.sort_first));
     if (b.sort_first > 0) {
-        hipLaunchKernelGGL(k_sort_fix, dim3((a.n + 255) / 256), dim3(256), 0, s, b.keys[0], b.idx[0], a.n, b.cut);
+        const int blocks = (a.n + 255) / 256;
+        hipLaunchKernelGGL(k_sort_fix, dim3(blocks < SORT_FIX_BLOCKS ? blocks : SORT_FIX_BLOCKS), dim3(256), 0, s, b.keys[0],
+                           b.idx[0], a.n, b.cut);
         NB_HIP(hipGetLastError());
     }
     return NB_OK;
