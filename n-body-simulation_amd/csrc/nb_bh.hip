@@ -269,14 +269,13 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     const uint32_t hint = (b.pc_range && b.hint_host) ? *(volatile const uint32_t *)b.hint_host : 0xffffffffu;
     b.use_pyr = hint <= (uint32_t)PYR_MAX_LEVEL;
     b.pyr_levels = b.use_pyr ? PYR_MAX_LEVEL : -1;  // the deepest key level the pyramid kernels can do
-    // The sort's passes below the keys' digits would return at once, at a launch each: they are
-    // not launched, with one pass to spare below what the last known keys needed.
+    // The sort's passes below the keys' digits would return at once, at a launch each (13 us for the
+    // three kernels of an idle pass at N = 5 M): they are not launched.  The hint already is the
+    // level a box a tenth larger would need, and the host runs at most three steps ahead; a step
+    // whose keys still outgrow the launched passes is finished by k_sort_fix.
     b.sort_first = 0;
-    if (hint <= (uint32_t)BH_KEY_LEVELS) {
-        b.sort_first = sort_first_pass(2 * (int)hint) - 1;
-        if (b.sort_first < 0)
-            b.sort_first = 0;
-    }
+    if (hint <= (uint32_t)BH_KEY_LEVELS)
+        b.sort_first = sort_first_pass(2 * (int)hint);
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, b.bbox_part, blocks, a.bbox_margin, a.bucket_depth,
                        a.theta, a.collision_th, b.box, b.cut, b.pyr_levels, b.hint_host, b.hint_box, -1, (uint32_t *)nullptr,
                        a.n, b.sort_first, box_ring_slot(b));

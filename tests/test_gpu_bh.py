@@ -666,8 +666,8 @@ def test_long_tree_run_renews_its_order_by_itself(nb, oracle, dims):
 
 @pytest.mark.parametrize("speed", [2.5e10, 1.0e12])
 def test_sort_is_finished_when_the_keys_outgrow_the_launched_passes(nb, oracle, speed):
-    """The host launches only the sort passes the keys of the last step it knows needed, plus one
-    below.  A body leaving at an absurd speed widens the box hundreds (or tens of thousands) of
+    """The host launches only the sort passes the keys of the last step it knows would need with a
+    box a tenth larger.  A body leaving at an absurd speed widens the box hundreds (or tens of thousands) of
     times within one step: the keys of the next evaluation need passes that were not launched, and
     the device finishes the order itself.  Keys and sorted order must be the reference's to the bit
     (the accelerations cannot be checked at the usual bar: float coordinates no longer resolve the
