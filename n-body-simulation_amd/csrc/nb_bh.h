@@ -67,6 +67,7 @@ struct BhBuffers {
     uint32_t *err = nullptr;          // (unused device word kept beside them)
     bool use_pyr = false;             // this step's kernels are launched for the dense-pyramid build ...
     int pyr_levels = -1;              // ... and can do keys of up to this many levels (-1: not launched)
+    int pyr_max = 10;                 // the deepest key level the pyramid of these buffers has slots for
     int sort_first = 0;               // the first sort pass this step's launches include
 };
 

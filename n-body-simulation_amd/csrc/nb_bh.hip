@@ -33,9 +33,15 @@ namespace nb {
 // children of a cell are the consecutive slots pyr_offset(l + 1) + 4 c .. + 3 and nothing has to be
 // numbered or searched for.
 constexpr int PYR_MAX_LEVEL = 10;
+// Systems whose 2 n node slots hold the cells of one more level anyway get the pyramid down to
+// level 11 (a collision run whose ejected bodies stretch the box reaches it): BhBuffers::pyr_max.
+#ifndef NB_PYR_DEEP_LEVEL
+#define NB_PYR_DEEP_LEVEL 11
+#endif
+constexpr int PYR_DEEP_LEVEL = NB_PYR_DEEP_LEVEL;  // (10 switches the deeper pyramid off: tuning aid)
 __host__ __device__ constexpr uint32_t pyr_offset(int l) { return (uint32_t)((((uint64_t)1 << (2 * l)) - 1) / 3); }
 constexpr uint32_t PYR_CELLS = pyr_offset(PYR_MAX_LEVEL + 1);        // cells of all levels
-constexpr uint32_t PYR_LEAF_CELLS = 1u << (2 * PYR_MAX_LEVEL);        // cells of the deepest level
+constexpr uint32_t PYR_DEEP_CELLS = pyr_offset(PYR_DEEP_LEVEL + 1);
 
 // ------------------------------------------------------------------ 1 bounding box
 
@@ -267,8 +273,10 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     // which build this step's kernels are launched for: the dense pyramid when the keys of the last
     // finished step stopped at a level it covers
     const uint32_t hint = (b.pc_range && b.hint_host) ? *(volatile const uint32_t *)b.hint_host : 0xffffffffu;
-    b.use_pyr = hint <= (uint32_t)PYR_MAX_LEVEL;
-    b.pyr_levels = b.use_pyr ? PYR_MAX_LEVEL : -1;  // the deepest key level the pyramid kernels can do
+    b.use_pyr = hint <= (uint32_t)b.pyr_max;
+    // the deepest key level the pyramid kernels launched for this step can do (k_pyr_mid is only
+    // launched when the hint is beyond PYR_MAX_LEVEL; deeper keys than that take the fallback)
+    b.pyr_levels = !b.use_pyr ? -1 : (hint > (uint32_t)PYR_MAX_LEVEL ? b.pyr_max : PYR_MAX_LEVEL);
     // The sort's passes below the keys' digits would return at once, at a launch each (13 us for the
     // three kernels of an idle pass at N = 5 M): they are not launched.  The hint already is the
     // level a box a tenth larger would need, and the host runs at most three steps ahead; a step
@@ -1679,12 +1687,16 @@ __device__ __forceinline__ PyrCell pyr_combine(const ComArgs &a, const PyrCell *
 
 // The pyramid is cut at level r = pyr_split(L): k_pyr_sub gives every cell of level r a block that
 // builds levels r..L under it bottom-up in LDS (at most 4 levels below the block's cell: 341
-// cells); k_pyr_top then builds levels r-1..0 in one block, also in LDS.
+// cells); k_pyr_top then builds levels r-1..0 in one block, also in LDS.  With L = 11 the cut is at
+// level 7, 16384 cells, too many for one block: k_pyr_mid takes levels 6..3 in between, again a
+// block per cell of its top level, and k_pyr_top starts from level pyr_top_from(L) = 3.
 __host__ __device__ constexpr int pyr_split(int L) { return L > 4 ? L - 4 : 0; }
+__host__ __device__ constexpr int pyr_top_from(int L) { return L > PYR_MAX_LEVEL ? pyr_split(L) - 4 : pyr_split(L); }
 constexpr int PYR_SUB_CELLS = 341;   // 1 + 4 + 16 + 64 + 256
 constexpr int PYR_TOP_CELLS = 1365;  // levels 0..5 ...
 constexpr int PYR_TOP_STAGE = 512;   // ... and, when r = 6, the level-6 cells in batches of this many
-static_assert(pyr_split(PYR_MAX_LEVEL) <= 6, "k_pyr_top stages at most one level beyond the six it holds");
+static_assert(pyr_top_from(PYR_MAX_LEVEL) <= 6 && pyr_top_from(PYR_DEEP_LEVEL) <= 6 && pyr_top_from(PYR_DEEP_LEVEL) >= 0,
+              "k_pyr_top stages at most one level beyond the six it holds");
 
 // The sums of pyr_short_sums / pyr_long_sums for the cell of every thread of a 256-thread block
 // (all threads call; range = {first, end} of the thread's cell, {0, 0} for none).  Long runs are
@@ -1876,6 +1888,39 @@ __global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, co
     }
 }
 
+// Levels r - 1 .. r - 4 of a pyramid deeper than PYR_MAX_LEVEL (r = pyr_split(L)): one block per
+// cell of level r - 4 reads the 256 cells of level r under it, which k_pyr_sub stored, and builds
+// the four levels above them in LDS.  Launched whenever the host expects such keys; a step whose
+// keys stop earlier has nothing for it to do.
+__global__ __launch_bounds__(256) void k_pyr_mid(ComArgs a, uint4 *node_meta)
+{
+    if (a.cut[3] == 0u)
+        return;
+    const int L = (int)a.cut[4];
+    if (L <= PYR_MAX_LEVEL)
+        return;
+    __shared__ PyrCell cells[PYR_SUB_CELLS];  // levels r - 4 .. r of the block's cell
+    const int r = pyr_split(L), r2 = pyr_top_from(L);
+    const int sub = r - r2;                   // 4
+    const uint32_t nroots = 1u << (2 * r2), nleaf = 1u << (2 * sub);
+    const double width0 = a.box[2] - a.box[0];
+    for (uint32_t root = blockIdx.x; root < nroots; root += gridDim.x) {
+        for (uint32_t t = threadIdx.x; t < nleaf; t += 256)
+            cells[pyr_offset(sub) + t] = pyr_load(a, node_meta, pyr_offset(r) + root * nleaf + t);
+        __syncthreads();
+        for (int k = sub - 1; k >= 0; --k) {
+            const uint32_t cnt = 1u << (2 * k);
+            for (uint32_t t = threadIdx.x; t < cnt; t += 256) {
+                const uint32_t c = root * cnt + t;  // the cell's index within level r2 + k
+                const PyrCell me = pyr_combine(a, &cells[pyr_offset(k + 1) + 4 * t], pyr_offset(r2 + k + 1) + 4 * c, r2 + k, width0);
+                cells[pyr_offset(k) + t] = me;
+                pyr_store(a, node_meta, pyr_offset(r2 + k) + c, me);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 constexpr int COM_TOP_LEVELS = 5;  // levels 0..4: at most 341 cells
 
 // The last launch of the dense-pyramid build, one block.  Normally: levels r - 1 .. 0 of the
@@ -1922,7 +1967,7 @@ __global__ __launch_bounds__(256) void k_pyr_top(ComArgs a, uint4 *node_meta, ui
         return;
     }
     const int L = (int)a.cut[4];
-    const int r = pyr_split(L);
+    const int r = pyr_top_from(L);  // the deepest level already stored (by k_pyr_sub or k_pyr_mid)
     const double width0 = a.box[2] - a.box[0];
     int held = r;  // the level held in LDS from which the sweep goes on
     if (r > 5) {
@@ -1976,8 +2021,11 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
         // one block per cell of the split level of the previous steps' keys (blocks go round if this
         // step's keys are deeper)
         const uint32_t hint = *(volatile const uint32_t *)b.hint_host;
-        const dim3 grid(1u << (2 * pyr_split((int)(hint <= (uint32_t)PYR_MAX_LEVEL ? hint : (uint32_t)PYR_MAX_LEVEL))));
+        const int deepest = (int)(hint <= (uint32_t)b.pyr_max ? hint : (uint32_t)b.pyr_max);
+        const dim3 grid(1u << (2 * pyr_split(deepest)));
         hipLaunchKernelGGL(k_pyr_sub<false>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range, (const double *)nullptr);
+        if (b.pyr_levels > PYR_MAX_LEVEL)
+            hipLaunchKernelGGL(k_pyr_mid, dim3(1u << (2 * pyr_top_from(PYR_DEEP_LEVEL))), dim3(256), 0, s, c, b.node_meta);
         hipLaunchKernelGGL(k_pyr_top, dim3(1), dim3(256), 0, s, c, b.node_meta, b.level_start, b.counters, b.keys[b.sorted],
                            (Split<2> *)b.split, b.bsum, a.n, b.levels_host, b.chunk_info);
         NB_HIP(hipGetLastError());
@@ -2696,6 +2744,7 @@ static int bh_layout(BhBuffers &b, int n, bool with_pyramid, Alloc &&alloc)
     b.node_cap = 2 * (size_t)n + 8;
     if (with_pyramid && b.node_cap < PYR_CELLS)
         b.node_cap = PYR_CELLS;  // the dense pyramid uses one node slot per cell
+    b.pyr_max = (with_pyramid && b.node_cap >= PYR_DEEP_CELLS) ? PYR_DEEP_LEVEL : PYR_MAX_LEVEL;
     b.sort_blocks = sort_blocks(n);
     NB_TRY(alloc(b.box, 4));
     NB_TRY(alloc(b.cut, 8));
@@ -2721,7 +2770,7 @@ static int bh_layout(BhBuffers &b, int n, bool with_pyramid, Alloc &&alloc)
     NB_TRY(alloc(b.counters, 8));
     if (with_pyramid) {
         // first / one-past-last sorted body of every cell of the deepest pyramid level
-        NB_TRY(alloc(b.pc_range, (size_t)PYR_LEAF_CELLS));
+        NB_TRY(alloc(b.pc_range, (size_t)1 << (2 * b.pyr_max)));
     }
     return NB_OK;
 }

@@ -550,6 +550,42 @@ def test_spiral_50m_matches_the_reference_tree(nb, oracle, capsys):
     assert err.max() <= ACC_EXPECTED, err.max()
 
 
+def test_pyramid_down_to_level_11(nb, oracle):
+    """A system large enough that its node slots hold the cells of level 11 anyway (N >= 2.8 M)
+    builds the dense pyramid down to that level: one body far outside stretches the box of a
+    3 M-body spiral 3.7 times, the tree closes at level 11 instead of 9, and the pyramid kernels
+    (with the middle kernel that takes levels 6..3) must give the reference's tree: every body in
+    exactly one leaf, sampled bodies at the oracle tree's accelerations (bar 1e-4: the float
+    coordinates resolve a box 3.7 times the system's size), also two steps on."""
+    n = 3000000
+    b = nb.init_scenario(nb.SPIRAL, n, 4242)
+    b["pos"][7] = (3.2e12, 1.0e11)
+    b["vel"][7] = (0.0, 0.0)
+    with nb.NBodySim(n, nb.BARNES_HUT) as sim:
+        sim.set_bodies(b)
+        acc = sim.compute_accel()
+        closed, levels = (int(v) for v in sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2))
+        cnt = sim.debug(nb.DBG_COUNTERS, np.uint64, 8)
+        ls, rng_, ch, _ = tree_arrays(nb, sim)
+        sim.update(2)
+        mid = sim.read_bodies()
+        acc2 = sim.compute_accel()
+        levels2 = int(sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2)[1])
+        cnt2 = sim.debug(nb.DBG_COUNTERS, np.uint64, 8)
+    assert closed == 11 and levels == 11 and levels2 == 11, (closed, levels, levels2)
+    # every cell of levels 0..11 is a node slot: the dense pyramid built this tree, both times
+    assert int(cnt[2]) == (4 ** 12 - 1) // 3 and int(cnt2[2]) == (4 ** 12 - 1) // 3, (cnt[2], cnt2[2])
+    assert np.all(np.isfinite(acc)) and np.all(np.isfinite(acc2))
+    nodes, _, kids = walk_tree(rng_, ch)
+    leaves = np.array([u for u in nodes if len(kids[int(u)]) == 0])
+    assert int(rng_[leaves, 1].astype(np.int64).sum()) == n
+    targets = sampled_targets(b, 256, 3)
+    err = rel_err(acc[targets], oracle.bh_accel_list(b, targets))
+    assert err.max() <= ACC_TOL, err.max()
+    err2 = rel_err(acc2[targets], oracle.bh_accel_list(mid, targets))
+    assert err2.max() <= ACC_TOL, err2.max()
+
+
 @pytest.mark.parametrize("dims", [2, 3])
 def test_deep_clustered_tree_stresses_the_traversal_stack(nb, oracle, dims):
     """No cutoff (so no level is closed), a small opening angle and a clump that shrinks geometrically
