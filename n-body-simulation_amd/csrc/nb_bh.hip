@@ -2172,12 +2172,17 @@ __global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         return;  // whole wave idle (no block barriers below)
     const int k = valid ? (a.tlist ? (int)a.tlist[slot] : slot) : 0;
     const uint32_t body = a.idx[k];
-    const double2 pd = a.pos[body];
-    const double rd = a.radius[body];
-    // the target in the float coordinates of this step's records (ComArgs: relative to the middle of the box)
-    const float xi = (float)((pd.x - 0.5 * (a.box[0] + a.box[2])) * a.inv_len);
-    const float yi = (float)((pd.y - 0.5 * (a.box[1] + a.box[3])) * a.inv_len);
-    const float ri = (float)(rd * a.inv_len);
+    // (the FP64 position and radius of the lane's body are read again where the rare FP64
+    // re-decisions and the epilogue need them: six registers the hot loops can use)
+    const double2 *const pp = a.pos + body;
+    float xi, yi, ri;
+    {
+        const double2 pd = *pp;
+        // the target in the float coordinates of this step's records (ComArgs: relative to the middle of the box)
+        xi = (float)((pd.x - 0.5 * (a.box[0] + a.box[2])) * a.inv_len);
+        yi = (float)((pd.y - 0.5 * (a.box[1] + a.box[3])) * a.inv_len);
+        ri = (float)(a.radius[body] * a.inv_len);
+    }
     const bool dynamic = valid && a.dyn[body];
     // BarnesHut::isCollide(Body, Vector): 2 r_i + th > dist drops an accepted cell (barnesHut.cpp:131-134)
     const float thn = 2.f * ri + a.fc.cth;
@@ -2351,11 +2356,12 @@ __global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 
             if ((ambm & mj) != 0ull) {
                 // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
                 const double *nc = a.node_com + 4 * (size_t)node_of(j);
+                const double2 pd = *pp;
                 const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
                 const double dist = sqrt(ex * ex + ey * ey);
                 accm = __builtin_amdgcn_ballot_w64(nc[3] / dist < a.theta);
                 if (!FAR)
-                    farm = __builtin_amdgcn_ballot_w64(!(rd * 2 + a.collision_th > dist));
+                    farm = __builtin_amdgcn_ballot_w64(!(a.radius[body] * 2 + a.collision_th > dist));
                 if (STATS)
                     n_recheck += 1;
             }
@@ -2454,9 +2460,10 @@ __global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 
             const uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= t2 * TR_BAND) & mj;
             if (ambm != 0ull) {
                 const double *nc = a.node_com + 4 * (size_t)node_of(j);
+                const double2 pd = *pp;
                 const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
                 const double dist = sqrt(ex * ex + ey * ey);
-                passm = __builtin_amdgcn_ballot_w64(!(rd + (-nc[3]) + a.collision_th > dist));
+                passm = __builtin_amdgcn_ballot_w64(!(a.radius[body] + (-nc[3]) + a.collision_th > dist));
                 if (STATS)
                     n_recheck += 1;
             }
@@ -2505,7 +2512,7 @@ __global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 
     if (a.ia.do_integrate && (dynamic || !a.ia.static_fixed)) {
         const double2 aa = dynamic ? make_double2(ax, ay) : a.acc[body];
         double2 v = a.vel[body];
-        double2 p = pd;
+        double2 p = *pp;
         v.x += aa.x * a.ia.dt_kick;
         v.y += aa.y * a.ia.dt_kick;
         p.x += v.x * a.ia.dt;

@@ -514,8 +514,12 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
 #endif
 constexpr int TR3_WPB = NB_TR3_WPB;  // waves per block: they share nothing, one per block packs the CUs best (7.27 -> 6.97 ms)
 
+#ifndef NB_TR3_OCC
+#define NB_TR3_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(64 * TR3_WPB) void k_bh3_force(Force3Args a)
+__global__ __launch_bounds__(64 * TR3_WPB) NB_TR3_OCC void k_bh3_force(Force3Args a)
 {
     __shared__ uint32_t st_node[TR3_WPB][TR3_STACK];
     __shared__ uint64_t st_mask[TR3_WPB][TR3_STACK];
@@ -545,8 +549,9 @@ __global__ __launch_bounds__(64 * TR3_WPB) void k_bh3_force(Force3Args a)
     const float thn2 = thn * thn, thn2_band = thn2 * TR3_BAND;
     const bool self_test = !(a.fc.cth > 0.f);
     const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
-    const double pdx = a.pos[3 * (size_t)body], pdy = a.pos[3 * (size_t)body + 1], pdz = a.pos[3 * (size_t)body + 2];
-    const double rd = a.radius[body];
+    // (the FP64 position and radius of the lane's body are read where the rare FP64 re-decisions
+    // and the epilogue need them: held in registers they would cost the eighth wave per SIMD)
+    const double *const pd = a.pos + 3 * (size_t)body;
     // bounding box of the wave's targets and their largest cell cutoff (see k_bh_force)
     float g0[3] = {xi, yi, zi}, g1[3] = {xi, yi, zi}, safe2 = thn2;
 #pragma unroll
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(64 * TR3_WPB) void k_bh3_force(Force3Args a)
             return (uint32_t)__builtin_amdgcn_readlane((int)u, (int)__builtin_ctzll(at));
         };
         auto dist64 = [&](const double *nc) {
-            const double qx = nc[0] - pdx, qy = nc[1] - pdy, qz = nc[2] - pdz;
+            const double qx = nc[0] - pd[0], qy = nc[1] - pd[1], qz = nc[2] - pd[2];
             return sqrt(qx * qx + qy * qy + qz * qz);
         };
         // ---- cells: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(64 * TR3_WPB) void k_bh3_force(Force3Args a)
                 const double dist = dist64(nc);
                 accm = __builtin_amdgcn_ballot_w64(nc[4] / dist < a.theta);
                 if (!FAR)
-                    farm = __builtin_amdgcn_ballot_w64(!(rd * 2 + a.collision_th > dist));
+                    farm = __builtin_amdgcn_ballot_w64(!(a.radius[body] * 2 + a.collision_th > dist));
                 if (STATS)
                     n_recheck += 1;
             }
@@ -788,7 +793,7 @@ __global__ __launch_bounds__(64 * TR3_WPB) void k_bh3_force(Force3Args a)
             if (ambm != 0ull) {
                 const double *nc = a.node_com + 6 * (size_t)node_of(j);
                 const double dist = dist64(nc);
-                passm = __builtin_amdgcn_ballot_w64(!(rd + (-nc[4]) + a.collision_th > dist));
+                passm = __builtin_amdgcn_ballot_w64(!(a.radius[body] + (-nc[4]) + a.collision_th > dist));
                 if (STATS)
                     n_recheck += 1;
             }
@@ -839,11 +844,10 @@ __global__ __launch_bounds__(64 * TR3_WPB) void k_bh3_force(Force3Args a)
     }
     // every body is advanced with its own velocity (barnesHut.cpp:108-123)
     if (a.ia.do_integrate) {
-        const double p0[3] = {pdx, pdy, pdz};
         for (int d = 0; d < 3; ++d) {
             const double v = a.vel[3 * (size_t)body + d] + acc[d] * a.ia.dt_kick;
             a.vel[3 * (size_t)body + d] = v;
-            a.pos[3 * (size_t)body + d] = p0[d] + v * a.ia.dt;
+            a.pos[3 * (size_t)body + d] = pd[d] + v * a.ia.dt;
         }
     }
 }
