@@ -24,6 +24,7 @@
 
 #include "nb_bh.h"
 #include "nb_dev.h"
+#include "nb_traverse.h"
 
 namespace nb {
 
@@ -2070,35 +2071,30 @@ static ComArgs com_args(const BhBuffers &b, const BhStepArgs &a)
 }
 
 // ------------------------------------------------------------------ 6 traversal + integration
-
-// The stack holds one entry per opened node: {first child slot << 4 | mask of the child slots in
-// use, mask of the lanes that opened it}; the (up to 4) siblings share the lane mask.  A round pops
-// up to TR_ENTRIES entries and gives each a group of 4 lanes: lane 4 e + i takes child slot i of the
-// e-th entry from the top (lanes whose slot is not in use sit the round out).  Every visited node pushes at most one
-// entry.  Above TR_HIGH entries the wave pops one entry per round: a depth-first descent then
-// adds at most 3 entries per tree level (< 32 levels), on top of what the last full round
-// pushed, so TR_STACK - TR_HIGH >= 4 TR_ENTRIES + 3 * 32 rules out an overflow.
+//
+// The kernel is traverse_and_integrate<2> (nb_traverse.h, shared with the octree); this is what
+// the quadtree pipeline brings to it.  A stack entry is {first child slot << 4 | mask of the child
+// slots in use}; the four child slots of a cell are consecutive (dense pyramid: one per quadrant,
+// level-by-level build: packed).
 #ifndef NB_TR_ENTRIES
 #define NB_TR_ENTRIES 16
 #endif
 #ifndef NB_TR_HIGH
 #define NB_TR_HIGH 64
 #endif
-#ifndef NB_TR_FULL_UNROLL
-#define NB_TR_FULL_UNROLL 2
+// Waves per block.  The waves of a block share nothing, and a block's slot on its CU is free again
+// only when its slowest wave is done: one wave per block packs the CUs best (traversal at N = 5 M:
+// 1.00 ms with four, 0.99 with two, 0.97 with one).
+#ifndef NB_TR_WPB
+#define NB_TR_WPB 1
 #endif
-constexpr int TR_ENTRIES = NB_TR_ENTRIES;
-constexpr int TR_BATCH = 4 * TR_ENTRIES;  // most nodes a round can hold
-constexpr int TR_HIGH = NB_TR_HIGH;
-constexpr int TR_STACK = TR_HIGH + TR_BATCH + 3 * 32 + 1;  // entries per wave
-static_assert(TR_ENTRIES >= 1 && TR_ENTRIES <= 16, "one group of 4 lanes per popped entry");
 
 struct ForceArgs {
     const double *box;       // this step's bounding box (the origin of the float coordinates is its middle)
     double inv_len;          // 1 / length unit
-    const float4 *node_rec;
+    const float4 *node_rec;  // {x, y, mass, (width / theta)^2; for a body: -(r_j + th)}
     const uint2 *node_aux;   // x = first child slot << 4 | mask of the slots in use, y = float bits of the prune threshold
-    const double *node_com;
+    const double *node_com;  // {x, y, mass, width (for a body: -r_j)} in FP64, for the re-decisions
     const uint32_t *idx;
     const uint32_t *tlist;   // may be null: targets are all sorted bodies
     const uint32_t *tcount;  // device count of tlist entries (when tlist != null)
@@ -2115,411 +2111,72 @@ struct ForceArgs {
     double collision_th;
 };
 
-__device__ __forceinline__ float readlane_f(float v, int l)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-
-// A float comparison whose two sides differ by less than this fraction is repeated in FP64
-// on the FP64 positions.  The float distance of two bodies carries the rounding of their
-// coordinates (up to 2^-24 of the domain each), which near the cutoff distance is a few
-// 1e-6 of the distance; the band is several times that.
-constexpr float TR_BAND = 4.0e-5f;
-
-// Scale of the force of one accepted cell or body on the lane's target, m / r^3 with
-// r^2 = d^2 + eps2.  FM_EXACT keeps the reference's second softening term in the denominator
-// (r^3 + eps3); FM_NOEPS leaves eps out altogether: the host selects it when eps2 is below the
-// float resolution of every distance that can contribute (all are beyond the cutoff).
-enum { FM_NOEPS = 0, FM_EPS = 1, FM_EXACT = 2 };
-template <int MODE>
-__device__ __forceinline__ float force_scale(float d2, float nm, float eps2, float eps3)
-{
-    if (MODE == FM_EXACT) {
-        const float r2 = d2 + eps2;
-        const float r3 = r2 * __builtin_sqrtf(r2);
-        return nm * __builtin_amdgcn_rcpf(r3 + eps3);
-    }
-    const float rinv = __builtin_amdgcn_rsqf(MODE == FM_EPS ? d2 + eps2 : d2);
-    return ((rinv * rinv) * rinv) * nm;  // one dependent chain: as two products the compiler packs them, at a loss
-}
-
-// Waves per block.  The waves of a block share nothing, and a block's slot on its CU is free again
-// only when its slowest wave is done: one wave per block packs the CUs best (traversal at N = 5 M:
-// 1.00 ms with four, 0.99 with two, 0.97 with one).
-#ifndef NB_TR_WPB
-#define NB_TR_WPB 1
-#endif
-constexpr int TR_WPB = NB_TR_WPB;
-
-template <int MODE, bool STATS>
-__global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bh_force(ForceArgs a)
-{
-    __shared__ uint32_t st_node[TR_WPB][TR_STACK];
-    __shared__ uint64_t st_mask[TR_WPB][TR_STACK];
-    // the batch being visited: per entry {record} and {lane mask, child word, prune threshold}
-    __shared__ __attribute__((aligned(16))) uint4 st_batch[TR_WPB][TR_BATCH][2];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    uint32_t *snode = st_node[w];
-    uint64_t *smask = st_mask[w];
-    uint4(*batch)[2] = st_batch[w];
-
-    const int ntarget = a.tlist ? (int)*a.tcount : a.n;
-    // neighbouring groups of bodies visit mostly the same nodes: give them to one XCD's L2
-    const int wave = (int)xcd_chunked_block(blockIdx.x, gridDim.x) * TR_WPB + w;
-    const int slot = wave * 64 + lane;
-    const bool valid = slot < ntarget;
-    if (wave * 64 >= ntarget)
-        return;  // whole wave idle (no block barriers below)
-    const int k = valid ? (a.tlist ? (int)a.tlist[slot] : slot) : 0;
-    const uint32_t body = a.idx[k];
-    // (the FP64 position and radius of the lane's body are read again where the rare FP64
-    // re-decisions and the epilogue need them: six registers the hot loops can use)
-    const double2 *const pp = a.pos + body;
-    float xi, yi, ri;
+template <>
+struct Traversal<2> {
+    using Args = ForceArgs;
+    using Aux = uint2;
+    static constexpr int GROUP = 4, ENTRIES = NB_TR_ENTRIES, HIGH = NB_TR_HIGH, DEPTH = 32, WPB = NB_TR_WPB;
+    static constexpr bool EXTRA = false;      // the second staged word holds everything a visit needs
+    static constexpr int COM = 4, COM_W = 3;  // doubles per node_com record, index of the width
+    // the target in the float coordinates of this step's records (ComArgs: relative to the middle
+    // of the box); the traversal converts the FP64 position itself, no sorted record array exists
+    static __device__ __forceinline__ void load_target(const Args &a, int, uint32_t body, Pt<2> &x, float &ri)
     {
-        const double2 pd = *pp;
-        // the target in the float coordinates of this step's records (ComArgs: relative to the middle of the box)
-        xi = (float)((pd.x - 0.5 * (a.box[0] + a.box[2])) * a.inv_len);
-        yi = (float)((pd.y - 0.5 * (a.box[1] + a.box[3])) * a.inv_len);
+        const double2 pd = a.pos[body];
+        x.xy.x = (float)((pd.x - 0.5 * (a.box[0] + a.box[2])) * a.inv_len);
+        x.xy.y = (float)((pd.y - 0.5 * (a.box[1] + a.box[3])) * a.inv_len);
+        x.z = 0.f;
         ri = (float)(a.radius[body] * a.inv_len);
     }
-    const bool dynamic = valid && a.dyn[body];
-    // BarnesHut::isCollide(Body, Vector): 2 r_i + th > dist drops an accepted cell (barnesHut.cpp:131-134)
-    const float thn = 2.f * ri + a.fc.cth;
-    const float thn2 = thn * thn;
-    const float thn2_band = thn2 * TR_BAND;
-    // with a positive cutoff a body fails its own pair test (distance 0); only without one
-    // must the zero distance be excluded explicitly
-    const bool self_test = !(a.fc.cth > 0.f);
-    const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
-    // Bounding box of the wave's targets and their largest cell cutoff: a cell whose centre of
-    // mass is farther from the box than that (with a margin far above float rounding) passes
-    // the cutoff test for every lane and cannot be pruned.  A batch made of such cells only is
-    // visited by a loop without those tests.
-    float gx0 = xi, gx1 = xi, gy0 = yi, gy1 = yi, safe2 = thn2;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        gx0 = fminf(gx0, __shfl_xor(gx0, o));
-        gx1 = fmaxf(gx1, __shfl_xor(gx1, o));
-        gy0 = fminf(gy0, __shfl_xor(gy0, o));
-        gy1 = fmaxf(gy1, __shfl_xor(gy1, o));
-        safe2 = fmaxf(safe2, __shfl_xor(safe2, o));
-    }
-    safe2 *= 1.001f;
-
-    double sx = 0.0, sy = 0.0;
-    unsigned long long n_eval = 0, n_acc = 0, n_recheck = 0, n_visit = 0, n_batch = 0;
-    int max_top = 0;
-
-    int top = 0;
-    // every lane the wave computes a force for; a node visited for all of them needs no lane mask
-    const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
+    static __device__ __forceinline__ bool has(uint32_t entry, int sib) { return (entry >> sib) & 1u; }
+    static __device__ __forceinline__ Aux no_aux() { return make_uint2(0u, 0u); }
+    static __device__ __forceinline__ uint32_t wbits(const float4 &r, const Aux &) { return __float_as_uint(r.w); }
+    static __device__ __forceinline__ float mass(const float4 &r) { return r.z; }
+    static __device__ __forceinline__ Pt<2> point(const float4 &r)
     {
-        if (m0 != 0ull) {
-            if (lane == 0) {
-                snode[0] = 1u;  // the root as a group of one
-                smask[0] = m0;
-            }
-            top = 1;
-        }
+        Pt<2> p;
+        p.xy = v2f{r.x, r.y};
+        p.z = 0.f;
+        return p;
     }
-    while (top > 0) {
-        if (STATS) {
-            n_batch += 1;
-            max_top = top > max_top ? top : max_top;
-        }
-        // Pop: the group of 4 lanes e takes the e-th entry from the top, lane i of it sibling i.
-        int npop = top < TR_ENTRIES ? top : TR_ENTRIES;
-        if (top > TR_HIGH)
-            npop = 1;
-        const int grp = lane >> 2, sib = lane & 3;
-        uint32_t u = 0;
-        uint64_t um = 0ull;
-        bool have = false;
-        if (grp < npop) {
-            const uint32_t ew = snode[top - 1 - grp];
-            have = (ew >> sib) & 1u;
-            u = (ew >> 4) + (uint32_t)sib;
-            um = smask[top - 1 - grp];
-        }
-        const uint64_t cmask = __builtin_amdgcn_ballot_w64(have);  // lanes holding a node
-        const int base = top - npop;
-        __builtin_amdgcn_wave_barrier();
-        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint2 aux = make_uint2(0u, 0u);
-        if (have) {
-            rec = a.node_rec[u];
-            aux = a.node_aux[u];
-        }
-        top = base;
-        // Each popped node is first judged for the wave as a whole, by the distance of its centre
-        // of mass to the bounding box of the wave's targets (margins far above float rounding):
-        //   opened by every lane   -> its children go onto the stack right here, no visit;
-        //   accepted by every lane -> visited by a loop that only adds the force;
-        //   far from every lane    -> visited without the cutoff and prune tests;
-        // the remaining cells and the bodies take the full tests.  Only cells beyond the largest
-        // cutoff distance of the wave take the first two shortcuts, so neither the cutoff nor
-        // the pruning rule can apply to them.
-        const float ex = fmaxf(fmaxf(gx0 - rec.x, rec.x - gx1), 0.f), ey = fmaxf(fmaxf(gy0 - rec.y, rec.y - gy1), 0.f);
-        const float fxm = fmaxf(rec.x - gx0, gx1 - rec.x), fym = fmaxf(rec.y - gy0, gy1 - rec.y);
-        const float dmin2 = __builtin_fmaf(ex, ex, ey * ey), dmax2 = __builtin_fmaf(fxm, fxm, fym * fym);
-        const uint64_t bodym = __builtin_amdgcn_ballot_w64((int)__float_as_uint(rec.w) < 0) & cmask;
-        const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~bodym;
-        const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < rec.w * 0.999f) & farm_all;
-        const uint64_t sureall = __builtin_amdgcn_ballot_w64(dmin2 > rec.w * 1.001f) & farm_all;
-        const uint64_t farcm = farm_all & ~(openm | sureall);
-        // accepted by every lane AND visited for all of the wave's lanes: the plain force loop
-        const uint64_t fullm = sureall & __builtin_amdgcn_ballot_w64(um == m0);
-        const uint64_t surem = sureall & ~fullm;
-        const uint64_t nearm = cmask & ~(bodym | farm_all);
-        if (openm != 0ull) {
-            // one entry per opened node that has children
-            const uint64_t pushm = openm & __builtin_amdgcn_ballot_w64((aux.x & 15u) != 0u);
-            if (__builtin_amdgcn_inverse_ballot_w64(pushm)) {
-                const int at = top + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pushm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushm, 0u));
-                snode[at] = aux.x;
-                smask[at] = um;
-            }
-            top += (int)__popcll(pushm);
-            if (STATS) {
-                n_visit += (unsigned long long)__popcll(openm);
-                const uint64_t evals = __builtin_amdgcn_inverse_ballot_w64(openm) ? (uint64_t)__popcll(um) : 0ull;
-                unsigned long long e = evals;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1)
-                    e += __shfl_xor(e, o);
-                n_eval += e;
-            }
-        }
-        // Stage the rest in LDS, by kind: every lane then reads entry j with the same address (an
-        // LDS broadcast), which keeps the per-node data off the vector ALU's lane-read path, and
-        // each kind of node gets a loop without the other kinds' code.
-        const int nfull = (int)__popcll(fullm), nsure = nfull + (int)__popcll(surem);
-        const int nfar = nsure + (int)__popcll(farcm), ncell = nfar + (int)__popcll(nearm);
-        const int cstaged = ncell + (int)__popcll(bodym);
-        int slot_j;
-        {
-            const int r_full = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fullm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fullm, 0u));
-            const int r_sure = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(surem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)surem, 0u));
-            const int r_far = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(farcm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)farcm, 0u));
-            const int r_near = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nearm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nearm, 0u));
-            const int r_body = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bodym >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bodym, 0u));
-            slot_j = r_full;
-            slot_j = __builtin_amdgcn_inverse_ballot_w64(surem) ? nfull + r_sure : slot_j;
-            slot_j = __builtin_amdgcn_inverse_ballot_w64(farcm) ? nsure + r_far : slot_j;
-            slot_j = __builtin_amdgcn_inverse_ballot_w64(nearm) ? nfar + r_near : slot_j;
-            slot_j = __builtin_amdgcn_inverse_ballot_w64(bodym) ? ncell + r_body : slot_j;
-        }
-        const bool staged = __builtin_amdgcn_inverse_ballot_w64(cmask & ~openm);
-        if (staged) {
-            batch[slot_j][0] = make_uint4(__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z),
-                                          __float_as_uint(rec.w));
-            batch[slot_j][1] = make_uint4((uint32_t)um, (uint32_t)(um >> 32), aux.x, aux.y);
-        }
-        __builtin_amdgcn_wave_barrier();
-        float fx = 0.f, fy = 0.f;
-        // node index of batch entry j (only the rare FP64 re-decisions need it)
-        auto node_of = [&](int j) {
-            j = __builtin_amdgcn_readfirstlane(j);  // opaque: keeps a running copy of slot_j - j out of the loop
-            const uint64_t at = __builtin_amdgcn_ballot_w64(staged && slot_j == j);
-            return (uint32_t)__builtin_amdgcn_readlane((int)u, (int)__builtin_ctzll(at));
-        };
-        // Per-lane conditions are kept as 64-bit lane masks in scalar registers (the result of a
-        // vector compare IS such a mask), so combining them costs scalar instructions only.
-        // ---- cells: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
-        auto visit_cell = [&](const int j, auto far_tag) {
-            constexpr bool FAR = decltype(far_tag)::value;
-            const uint4 r = batch[j][0], q = batch[j][1];
-            const float nx = __uint_as_float(r.x), ny = __uint_as_float(r.y), nm = __uint_as_float(r.z);
-            const float nw = __uint_as_float(r.w);
-            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
-            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
-            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;  // lanes this node is visited for
-            const float dx = nx - xi, dy = ny - yi;
-            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-            const float g = d2 - nw;
-            uint64_t accm = __builtin_amdgcn_ballot_w64(g > 0.f);
-#ifdef NB_ABL_NOAMB
-            uint64_t ambm = 0ull;
-#else
-            uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= nw * TR_BAND);
-#endif
-            // an accepted cell counts only outside 2 r_i + th of its centre of mass (barnesHut.cpp:75)
-            uint64_t farm = ~0ull;
-            if (!FAR) {
-                const float g2 = d2 - thn2;
-                farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
-#ifndef NB_ABL_NOAMB
-                ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band);
-#endif
-            }
-            if ((ambm & mj) != 0ull) {
-                // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
-                const double *nc = a.node_com + 4 * (size_t)node_of(j);
-                const double2 pd = *pp;
-                const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
-                const double dist = sqrt(ex * ex + ey * ey);
-                accm = __builtin_amdgcn_ballot_w64(nc[3] / dist < a.theta);
-                if (!FAR)
-                    farm = __builtin_amdgcn_ballot_w64(!(a.radius[body] * 2 + a.collision_th > dist));
-                if (STATS)
-                    n_recheck += 1;
-            }
-            const uint64_t macc = mj & accm;
-            uint64_t okm = FAR ? macc : macc & farm;
-            // Nothing below a cell that lies wholly inside the cutoff distance can contribute:
-            // every body and every centre of mass in it is closer than collision_th.  A lane
-            // that sees the cell that way does not open it.
-            uint64_t om = mj ^ macc;
-            if (!FAR)
-                om &= ~__builtin_amdgcn_ballot_w64(d2 < __uint_as_float(q.w));
-            if (om != 0ull) {
-                const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
-                if ((packed & 15u) != 0u) {
-                    if (lane == 0) {
-                        snode[top] = packed;
-                        smask[top] = om;
-                    }
-                    top += 1;
-                }
-            }
-#ifdef NB_ABL_NOFORCE
-            okm = 0ull;
-#endif
-            if (okm != 0ull) {
-                asm volatile("" ::: "memory");  // keep the force arithmetic inside this branch
-                // lanes outside okm get a zero scale (their own may be inf or NaN: d2 can be 0)
-                const float sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? force_scale<MODE>(d2, nm, eps2, eps3) : 0.f;
-                fx = __builtin_fmaf(dx, sc, fx);
-                fy = __builtin_fmaf(dy, sc, fy);
-            }
-            if (STATS) {
-                n_eval += (unsigned long long)__popcll(mj);
-                n_acc += (unsigned long long)__popcll(okm);
-                n_visit += 1;
-            }
-        };
-        // ---- cells every lane accepts and that are visited for every lane the wave computes a
-        // force for (6 of 7 such cells at N = 5M): only the force, no lane mask.  A lane outside m0
-        // is a static or padding lane and sums values nobody reads.  Unrolled by 2 only: the
-        // compiler's own choice (8) costs 16 registers, i.e. two of the eight waves per SIMD. ----
-#pragma unroll NB_TR_FULL_UNROLL
-        for (int j = 0; j < nfull; ++j) {
-            const uint4 r = batch[j][0];
-            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi;
-            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-            const float sc = force_scale<MODE>(d2, __uint_as_float(r.z), eps2, eps3);
-            fx = __builtin_fmaf(dx, sc, fx);
-            fy = __builtin_fmaf(dy, sc, fy);
-            if (STATS) {
-                n_eval += (unsigned long long)__popcll(m0);
-                n_acc += (unsigned long long)__popcll(m0);
-                n_visit += 1;
-            }
-        }
-        // ---- cells every lane accepts: only the force, for the lanes the cell is visited for ----
-        for (int j = nfull; j < nsure; ++j) {
-            const uint4 r = batch[j][0];
-            const uint2 q = *(const uint2 *)&batch[j][1];
-            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
-            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
-            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
-            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi;
-            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-#ifndef NB_ABL_NOFORCE
-            const float sc = __builtin_amdgcn_inverse_ballot_w64(mj) ? force_scale<MODE>(d2, __uint_as_float(r.z), eps2, eps3) : 0.f;
-            fx = __builtin_fmaf(dx, sc, fx);
-            fy = __builtin_fmaf(dy, sc, fy);
-#endif
-            if (STATS) {
-                n_eval += (unsigned long long)__popcll(mj);
-                n_acc += (unsigned long long)__popcll(mj);
-                n_visit += 1;
-            }
-        }
-        for (int j = nsure; j < nfar; ++j)
-            visit_cell(j, std::true_type{});
-        for (int j = nfar; j < ncell; ++j)
-            visit_cell(j, std::false_type{});
-        // ---- bodies: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
-        for (int j = ncell; j < cstaged; ++j) {
-            const uint4 r = batch[j][0];
-            const uint2 q = *(const uint2 *)&batch[j][1];
-            const float nx = __uint_as_float(r.x), ny = __uint_as_float(r.y), nm = __uint_as_float(r.z);
-            const float nw = __uint_as_float(r.w);
-            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
-            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
-            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
-            const float dx = nx - xi, dy = ny - yi;
-            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-            const float th = ri - nw;
-            const float t2 = th * th;
-            const float g = d2 - t2;
-            uint64_t passm = __builtin_amdgcn_ballot_w64(g >= 0.f);
-#ifndef NB_ABL_NOAMB
-            const uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= t2 * TR_BAND) & mj;
-            if (ambm != 0ull) {
-                const double *nc = a.node_com + 4 * (size_t)node_of(j);
-                const double2 pd = *pp;
-                const double ex = nc[0] - pd.x, ey = nc[1] - pd.y;
-                const double dist = sqrt(ex * ex + ey * ey);
-                passm = __builtin_amdgcn_ballot_w64(!(a.radius[body] + (-nc[3]) + a.collision_th > dist));
-                if (STATS)
-                    n_recheck += 1;
-            }
-#endif
-            uint64_t okm = mj & passm;
-            if (self_test)  // the body itself has d2 == 0 (the reference skips it by pointer)
-                okm &= __builtin_amdgcn_ballot_w64(d2 > 0.f);
-#ifdef NB_ABL_NOFORCE
-            okm = 0ull;
-#endif
-            if (okm != 0ull) {
-                asm volatile("" ::: "memory");
-                const float sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? force_scale<MODE>(d2, nm, eps2, eps3) : 0.f;
-                fx = __builtin_fmaf(dx, sc, fx);
-                fy = __builtin_fmaf(dy, sc, fy);
-            }
-            if (STATS) {
-                n_eval += (unsigned long long)__popcll(mj);
-                n_acc += (unsigned long long)__popcll(okm);
-                n_visit += 1;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        sx += (double)fx;
-        sy += (double)fy;
+    static __device__ __forceinline__ uint32_t child(const Aux &x) { return x.x; }
+    static __device__ __forceinline__ uint4 stage(uint64_t um, const Aux &x)
+    {
+        return make_uint4((uint32_t)um, (uint32_t)(um >> 32), x.x, x.y);
     }
-
-    if (STATS && lane == 0) {
-        atomicAdd(&a.counters[0], n_eval);
-        atomicAdd(&a.counters[1], n_acc);
-        atomicAdd(&a.counters[4], n_recheck);
-        atomicAdd(&a.counters[5], n_visit);
-        atomicAdd(&a.counters[6], n_batch);
-        atomicMax(&a.counters[7], (unsigned long long)max_top);
+    static __device__ __forceinline__ float stage_extra(const Aux &) { return 0.f; }
+    static __device__ __forceinline__ float staged_width(const float4 &r, const uint4 &) { return r.w; }
+    static __device__ __forceinline__ float staged_prune(const uint4 &q, const float *, int) { return __uint_as_float(q.w); }
+    static __device__ __forceinline__ uint32_t staged_child(const uint4 &q) { return q.z; }
+    static __device__ __forceinline__ const double *pos_ptr(const Args &a, uint32_t body) { return (const double *)(a.pos + body); }
+    static __device__ __forceinline__ void store_acc(const Args &a, uint32_t body, const double (&acc)[2])
+    {
+        a.acc[body] = make_double2(acc[0], acc[1]);
     }
-    if (!valid)
-        return;
-    double ax = 0.0, ay = 0.0;
-    if (dynamic) {
-        ax = sx * a.ia.acc_factor;
-        ay = sy * a.ia.acc_factor;
-        a.acc[body] = make_double2(ax, ay);
+    static __device__ __forceinline__ void load_acc(const Args &a, uint32_t body, double (&acc)[2])
+    {
+        const double2 t = a.acc[body];
+        acc[0] = t.x;
+        acc[1] = t.y;
     }
-    // a static body keeps the acceleration it was given (calculateAcceleration, barnesHut.cpp:96-106)
-    // and every body is advanced with its own velocity (barnesHut.cpp:108-123)
-    if (a.ia.do_integrate && (dynamic || !a.ia.static_fixed)) {
-        const double2 aa = dynamic ? make_double2(ax, ay) : a.acc[body];
+    static __device__ __forceinline__ void integrate(const Args &a, uint32_t body, const double (&acc)[2])
+    {
         double2 v = a.vel[body];
-        double2 p = *pp;
-        v.x += aa.x * a.ia.dt_kick;
-        v.y += aa.y * a.ia.dt_kick;
+        double2 p = a.pos[body];
+        v.x += acc[0] * a.ia.dt_kick;
+        v.y += acc[1] * a.ia.dt_kick;
         p.x += v.x * a.ia.dt;
         p.y += v.y * a.ia.dt;
         a.vel[body] = v;
         a.pos[body] = p;
     }
+};
+constexpr int TR_WPB = Traversal<2>::WPB;
+
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bh_force(ForceArgs a)
+{
+    traverse_and_integrate<2, MODE, STATS>(a);
 }
 
 // ---- targets of this rank (multi-GPU): sorted positions k whose body lies in [t0, t1) ----

@@ -18,6 +18,7 @@
 #include "nb_bh.h"
 #include "nb_dev.h"
 #include "nb_dim3.h"
+#include "nb_traverse.h"
 
 namespace nb {
 
@@ -451,40 +452,34 @@ int bh3_com(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
 }
 
 // ------------------------------------------------------------------ 6 traversal + integration
-
-// The stack holds one entry per opened node: {first child << 4 | child count, mask of the lanes
-// that opened it}; the (up to 8) siblings share the mask.  A round pops up to TR3_ENTRIES entries
-// and gives each a group of 8 lanes: lane 8 e + i takes sibling i of the e-th entry from the top
-// (lanes past the entry's child count sit the round out), so no prefix sums are needed to
-// spread the nodes over the lanes.  Every visited node pushes at most one entry.  Above TR3_HIGH
-// entries the wave pops one entry per round: a depth-first descent then adds at most 7 entries
-// per tree level (21 levels), on top of what the last full round pushed, so
-// TR3_STACK - TR3_HIGH >= 8 TR3_ENTRIES + 7 * 21 rules out an overflow.
+//
+// The kernel is traverse_and_integrate<3> (nb_traverse.h, shared with the quadtree); this is what
+// the octree pipeline brings to it.  A stack entry is {first child << 4 | child count}: the (up to
+// 8) children of a cell are packed, and a round gives each popped entry a group of 8 lanes.  With one
+// stack entry per node the 440-entry stack cost occupancy and its rounds shrank to 9 nodes (11.0 ms
+// in the traversal at N = 5 M); entries per opened node with a prefix-sum pop: 8.2; lane groups: 7.45.
 #ifndef NB_TR3_HIGH
 #define NB_TR3_HIGH 64
 #endif
 #ifndef NB_TR3_ENTRIES
 #define NB_TR3_ENTRIES 6
 #endif
-constexpr int TR3_ENTRIES = NB_TR3_ENTRIES;
-constexpr int TR3_BATCH = 8 * TR3_ENTRIES;  // most nodes a round can hold
-constexpr int TR3_HIGH = NB_TR3_HIGH;
-constexpr int TR3_STACK = TR3_HIGH + TR3_BATCH + 7 * 21 + 1;  // entries per wave
-static_assert(TR3_ENTRIES >= 1 && TR3_ENTRIES <= 8, "one group of 8 lanes per popped entry");
-constexpr float TR3_BAND = 4.0e-5f;  // float comparisons closer than this are repeated in FP64
+#ifndef NB_TR3_WPB
+#define NB_TR3_WPB 1  // waves per block: they share nothing, one per block packs the CUs best (7.27 -> 6.97 ms)
+#endif
 
 struct Force3Args {
-    const float4 *posm_s;
-    const float *rad_s;
-    const float4 *node_rec;
-    const uint4 *node_aux;
-    const double *node_com;
+    const float4 *posm_s;    // {x, y, z, mass} of the sorted bodies, float coordinates of this step
+    const float *rad_s;      // their radii
+    const float4 *node_rec;  // {x, y, z, mass}
+    const uint4 *node_aux;   // x = float bits of (width / theta)^2 (a body: -(r_j + th)), y = first child << 4 | count, z = prune threshold
+    const double *node_com;  // {x, y, z, mass, width (a body: -r_j), -} in FP64, for the re-decisions
     const uint32_t *idx;
     const uint32_t *tlist;   // may be null: targets are all sorted bodies
     const uint32_t *tcount;  // device count of tlist entries (when tlist != null)
     const uint8_t *dyn;
     const double *radius;
-    double *pos, *vel, *acc;
+    double *pos, *vel, *acc;  // packed triples
     unsigned long long *counters;
     int n;
     ForceConsts fc;
@@ -492,364 +487,64 @@ struct Force3Args {
     double theta, collision_th;
 };
 
-enum { F3_NOEPS = 0, F3_EPS = 1, F3_EXACT = 2 };
-template <int MODE>
-__device__ __forceinline__ float force_scale3(float d2, float nm, float eps2, float eps3)
-{
-    if (MODE == F3_EXACT) {
-        const float r2 = d2 + eps2;
-        return nm * __builtin_amdgcn_rcpf(r2 * __builtin_sqrtf(r2) + eps3);
-    }
-    const float rinv = __builtin_amdgcn_rsqf(MODE == F3_EPS ? d2 + eps2 : d2);
-    return ((rinv * rinv) * rinv) * nm;
-}
-
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-#ifndef NB_TR3_WPB
-#define NB_TR3_WPB 1
-#endif
-constexpr int TR3_WPB = NB_TR3_WPB;  // waves per block: they share nothing, one per block packs the CUs best (7.27 -> 6.97 ms)
-
-#ifndef NB_TR3_OCC
-#define NB_TR3_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
-#endif
-
-template <int MODE, bool STATS>
-__global__ __launch_bounds__(64 * TR3_WPB) NB_TR3_OCC void k_bh3_force(Force3Args a)
-{
-    __shared__ uint32_t st_node[TR3_WPB][TR3_STACK];
-    __shared__ uint64_t st_mask[TR3_WPB][TR3_STACK];
-    // the batch being visited: per entry {record}, {lane mask, opening threshold, child word}
-    __shared__ __attribute__((aligned(16))) uint4 st_batch[TR3_WPB][TR3_BATCH][2];
-    __shared__ float st_prune[TR3_WPB][TR3_BATCH];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    uint32_t *snode = st_node[w];
-    uint64_t *smask = st_mask[w];
-    uint4(*batch)[2] = st_batch[w];
-    float *bprune = st_prune[w];
-
-    const int ntarget = a.tlist ? (int)*a.tcount : a.n;
-    const int wave = (int)xcd_chunked_block(blockIdx.x, gridDim.x) * TR3_WPB + w;  // see k_bh_force
-    const int slot = wave * 64 + lane;
-    if (wave * 64 >= ntarget)
-        return;  // whole wave idle (no block barriers below)
-    const bool valid = slot < ntarget;
-    const int last = valid ? slot : ntarget - 1;
-    const int ks = a.tlist ? (int)a.tlist[last] : last;
-    const uint32_t body = a.idx[ks];
-    const float4 me = a.posm_s[ks];
-    const float xi = me.x, yi = me.y, zi = me.z, ri = a.rad_s[ks];
-    const bool dynamic = valid && a.dyn[body];
-    // BarnesHut::isCollide(Body, Vector): 2 r_i + th > dist drops an accepted cell (barnesHut.cpp:131-134)
-    const float thn = 2.f * ri + a.fc.cth;
-    const float thn2 = thn * thn, thn2_band = thn2 * TR3_BAND;
-    const bool self_test = !(a.fc.cth > 0.f);
-    const float eps2 = a.fc.eps2, eps3 = a.fc.eps3;
-    // (the FP64 position and radius of the lane's body are read where the rare FP64 re-decisions
-    // and the epilogue need them: held in registers they would cost the eighth wave per SIMD)
-    const double *const pd = a.pos + 3 * (size_t)body;
-    // bounding box of the wave's targets and their largest cell cutoff (see k_bh_force)
-    float g0[3] = {xi, yi, zi}, g1[3] = {xi, yi, zi}, safe2 = thn2;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            g0[d] = fminf(g0[d], __shfl_xor(g0[d], o));
-            g1[d] = fmaxf(g1[d], __shfl_xor(g1[d], o));
-        }
-        safe2 = fmaxf(safe2, __shfl_xor(safe2, o));
-    }
-    safe2 *= 1.001f;
-
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    unsigned long long n_eval = 0, n_acc = 0, n_recheck = 0, n_visit = 0, n_batch = 0;
-    int max_top = 0;
-
-    int top = 0;
-    // every lane the wave computes a force for; a node visited for all of them needs no lane mask
-    const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
+template <>
+struct Traversal<3> {
+    using Args = Force3Args;
+    using Aux = uint4;
+    static constexpr int GROUP = 8, ENTRIES = NB_TR3_ENTRIES, HIGH = NB_TR3_HIGH, DEPTH = 21, WPB = NB_TR3_WPB;
+    static constexpr bool EXTRA = true;       // the prune threshold is staged beside the two words
+    static constexpr int COM = 6, COM_W = 4;  // doubles per node_com record, index of the width
+    static __device__ __forceinline__ void load_target(const Args &a, int k, uint32_t, Pt<3> &x, float &ri)
     {
-        if (m0 != 0ull) {
-            if (lane == 0) {
-                snode[0] = 1u;  // the root as a group of one
-                smask[0] = m0;
-            }
-            top = 1;
-        }
+        x = point(a.posm_s[k]);
+        ri = a.rad_s[k];
     }
-    while (top > 0) {
-        if (STATS) {
-            n_batch += 1;
-            max_top = top > max_top ? top : max_top;
-        }
-        // Pop: the group of 8 lanes e takes the e-th entry from the top, lane i of it sibling i.
-        int npop = top < TR3_ENTRIES ? top : TR3_ENTRIES;
-        if (top > TR3_HIGH)
-            npop = 1;
-        const int grp = lane >> 3, sib = lane & 7;
-        uint32_t u = 0;
-        uint64_t um = 0ull;
-        bool have = false;
-        if (grp < npop) {
-            const uint32_t ew = snode[top - 1 - grp];
-            have = (uint32_t)sib < (ew & 15u);
-            u = (ew >> 4) + (uint32_t)sib;
-            um = smask[top - 1 - grp];
-        }
-        const uint64_t cmask = __builtin_amdgcn_ballot_w64(have);  // lanes holding a node
-        const int base = top - npop;
-        __builtin_amdgcn_wave_barrier();
-        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint4 aux = make_uint4(0u, 0u, 0u, 0u);
-        if (have) {
-            rec = a.node_rec[u];
-            aux = a.node_aux[u];
-        }
-        top = base;
-        const float nw = __uint_as_float(aux.x);
-        // Each popped node is first judged for the wave as a whole by the distance of its centre of
-        // mass to the bounding box of the wave's targets: opened by every lane -> its children go
-        // onto the stack right here; accepted by every lane -> force only; far from every lane ->
-        // no cutoff and prune tests; the rest and the bodies take the full tests.
-        const float ex = fmaxf(fmaxf(g0[0] - rec.x, rec.x - g1[0]), 0.f), ey = fmaxf(fmaxf(g0[1] - rec.y, rec.y - g1[1]), 0.f),
-                    ez = fmaxf(fmaxf(g0[2] - rec.z, rec.z - g1[2]), 0.f);
-        const float fxm = fmaxf(rec.x - g0[0], g1[0] - rec.x), fym = fmaxf(rec.y - g0[1], g1[1] - rec.y),
-                    fzm = fmaxf(rec.z - g0[2], g1[2] - rec.z);
-        const float dmin2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
-        const float dmax2 = __builtin_fmaf(fxm, fxm, __builtin_fmaf(fym, fym, fzm * fzm));
-        const uint64_t bodym = __builtin_amdgcn_ballot_w64((int)aux.x < 0) & cmask;
-        const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~bodym;
-        const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < nw * 0.999f) & farm_all;
-        const uint64_t sureall = __builtin_amdgcn_ballot_w64(dmin2 > nw * 1.001f) & farm_all;
-        const uint64_t farcm = farm_all & ~(openm | sureall);
-        // accepted by every lane AND visited for all of the wave's lanes: the plain force loop
-        const uint64_t fullm = sureall & __builtin_amdgcn_ballot_w64(um == m0);
-        const uint64_t surem = sureall & ~fullm;
-        const uint64_t nearm = cmask & ~(bodym | farm_all);
-        if (openm != 0ull) {
-            // one entry per opened node that has children
-            const uint64_t pushm = openm & __builtin_amdgcn_ballot_w64((aux.y & 15u) != 0u);
-            if (__builtin_amdgcn_inverse_ballot_w64(pushm)) {
-                const int at = top + (int)mbcnt64(pushm);
-                snode[at] = aux.y;
-                smask[at] = um;
-            }
-            top += (int)__popcll(pushm);
-            if (STATS) {
-                n_visit += (unsigned long long)__popcll(openm);
-                unsigned long long e = __builtin_amdgcn_inverse_ballot_w64(openm) ? (unsigned long long)__popcll(um) : 0ull;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1)
-                    e += __shfl_xor(e, o);
-                n_eval += e;
-            }
-        }
-        // stage the rest in LDS by kind; every lane then reads entry j at the same address
-        const int nfull = (int)__popcll(fullm), nsure = nfull + (int)__popcll(surem);
-        const int nfar = nsure + (int)__popcll(farcm), ncell = nfar + (int)__popcll(nearm);
-        const int cstaged = ncell + (int)__popcll(bodym);
-        int slot_j = (int)mbcnt64(fullm);
-        slot_j = __builtin_amdgcn_inverse_ballot_w64(surem) ? nfull + (int)mbcnt64(surem) : slot_j;
-        slot_j = __builtin_amdgcn_inverse_ballot_w64(farcm) ? nsure + (int)mbcnt64(farcm) : slot_j;
-        slot_j = __builtin_amdgcn_inverse_ballot_w64(nearm) ? nfar + (int)mbcnt64(nearm) : slot_j;
-        slot_j = __builtin_amdgcn_inverse_ballot_w64(bodym) ? ncell + (int)mbcnt64(bodym) : slot_j;
-        const bool staged = __builtin_amdgcn_inverse_ballot_w64(cmask & ~openm);
-        if (staged) {
-            batch[slot_j][0] = make_uint4(__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z),
-                                          __float_as_uint(rec.w));
-            batch[slot_j][1] = make_uint4((uint32_t)um, (uint32_t)(um >> 32), aux.x, aux.y);
-            bprune[slot_j] = __uint_as_float(aux.z);
-        }
-        __builtin_amdgcn_wave_barrier();
-        float fx = 0.f, fy = 0.f, fz = 0.f;
-        // node index of batch entry j (only the rare FP64 re-decisions need it)
-        auto node_of = [&](int j) {
-            j = __builtin_amdgcn_readfirstlane(j);
-            const uint64_t at = __builtin_amdgcn_ballot_w64(staged && slot_j == j);
-            return (uint32_t)__builtin_amdgcn_readlane((int)u, (int)__builtin_ctzll(at));
-        };
-        auto dist64 = [&](const double *nc) {
-            const double qx = nc[0] - pd[0], qy = nc[1] - pd[1], qz = nc[2] - pd[2];
-            return sqrt(qx * qx + qy * qy + qz * qz);
-        };
-        // ---- cells: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
-        auto visit_cell = [&](const int j, auto far_tag) {
-            constexpr bool FAR = decltype(far_tag)::value;
-            const uint4 r = batch[j][0], q = batch[j][1];
-            const float nm = __uint_as_float(r.w), cw = __uint_as_float(q.z);
-            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
-            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
-            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;  // lanes this node is visited for
-            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi, dz = __uint_as_float(r.z) - zi;
-            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            const float g = d2 - cw;
-            uint64_t accm = __builtin_amdgcn_ballot_w64(g > 0.f);
-            uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= cw * TR3_BAND);
-            // an accepted cell counts only outside 2 r_i + th of its centre of mass (barnesHut.cpp:75)
-            uint64_t farm = ~0ull;
-            if (!FAR) {
-                const float g2 = d2 - thn2;
-                farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
-                ambm |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band);
-            }
-            if ((ambm & mj) != 0ull) {
-                // too close to call in float: decide in FP64 as the reference does (vector.cpp:31-35)
-                const double *nc = a.node_com + 6 * (size_t)node_of(j);
-                const double dist = dist64(nc);
-                accm = __builtin_amdgcn_ballot_w64(nc[4] / dist < a.theta);
-                if (!FAR)
-                    farm = __builtin_amdgcn_ballot_w64(!(a.radius[body] * 2 + a.collision_th > dist));
-                if (STATS)
-                    n_recheck += 1;
-            }
-            const uint64_t macc = mj & accm;
-            const uint64_t okm = FAR ? macc : macc & farm;
-            // a lane that sees the cell wholly inside its cutoff distance does not open it
-            uint64_t om = mj ^ macc;
-            if (!FAR)
-                om &= ~__builtin_amdgcn_ballot_w64(d2 < bprune[j]);
-            if (om != 0ull) {
-                const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w);
-                if ((packed & 15u) != 0u) {
-                    if (lane == 0) {
-                        snode[top] = packed;
-                        smask[top] = om;
-                    }
-                    top += 1;
-                }
-            }
-            if (okm != 0ull) {
-                asm volatile("" ::: "memory");  // keep the force arithmetic inside this branch
-                const float sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? force_scale3<MODE>(d2, nm, eps2, eps3) : 0.f;
-                fx = __builtin_fmaf(dx, sc, fx);
-                fy = __builtin_fmaf(dy, sc, fy);
-                fz = __builtin_fmaf(dz, sc, fz);
-            }
-            if (STATS) {
-                n_eval += (unsigned long long)__popcll(mj);
-                n_acc += (unsigned long long)__popcll(okm);
-                n_visit += 1;
-            }
-        };
-        // ---- cells every lane accepts and that are visited for every lane the wave computes a
-        // force for: only the force, no lane mask (a lane outside m0 is a static or padding lane
-        // and sums values nobody reads).  Unrolled by 2 only: more costs registers, i.e. waves. ----
-#pragma unroll 2
-        for (int j = 0; j < nfull; ++j) {
-            const uint4 r = batch[j][0];
-            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi, dz = __uint_as_float(r.z) - zi;
-            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            const float sc = force_scale3<MODE>(d2, __uint_as_float(r.w), eps2, eps3);
-            fx = __builtin_fmaf(dx, sc, fx);
-            fy = __builtin_fmaf(dy, sc, fy);
-            fz = __builtin_fmaf(dz, sc, fz);
-            if (STATS) {
-                n_eval += (unsigned long long)__popcll(m0);
-                n_acc += (unsigned long long)__popcll(m0);
-                n_visit += 1;
-            }
-        }
-        // ---- cells every lane accepts: only the force, for the lanes the cell is visited for ----
-        for (int j = nfull; j < nsure; ++j) {
-            const uint4 r = batch[j][0];
-            const uint2 q = *(const uint2 *)&batch[j][1];
-            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
-            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
-            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
-            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi, dz = __uint_as_float(r.z) - zi;
-            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            const float sc = __builtin_amdgcn_inverse_ballot_w64(mj) ? force_scale3<MODE>(d2, __uint_as_float(r.w), eps2, eps3) : 0.f;
-            fx = __builtin_fmaf(dx, sc, fx);
-            fy = __builtin_fmaf(dy, sc, fy);
-            fz = __builtin_fmaf(dz, sc, fz);
-            if (STATS) {
-                n_eval += (unsigned long long)__popcll(mj);
-                n_acc += (unsigned long long)__popcll(mj);
-                n_visit += 1;
-            }
-        }
-        for (int j = nsure; j < nfar; ++j)
-            visit_cell(j, std::true_type{});
-        for (int j = nfar; j < ncell; ++j)
-            visit_cell(j, std::false_type{});
-        // ---- bodies: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
-        for (int j = ncell; j < cstaged; ++j) {
-            const uint4 r = batch[j][0], q = batch[j][1];
-            const float nm = __uint_as_float(r.w), bw = __uint_as_float(q.z);  // bw = -(r_j + th)
-            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
-            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
-            const uint64_t mj = ((uint64_t)mhi << 32) | mlo;
-            const float dx = __uint_as_float(r.x) - xi, dy = __uint_as_float(r.y) - yi, dz = __uint_as_float(r.z) - zi;
-            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            const float th = ri - bw;
-            const float t2 = th * th;
-            const float g = d2 - t2;
-            uint64_t passm = __builtin_amdgcn_ballot_w64(g >= 0.f);
-            const uint64_t ambm = __builtin_amdgcn_ballot_w64(__builtin_fabsf(g) <= t2 * TR3_BAND) & mj;
-            if (ambm != 0ull) {
-                const double *nc = a.node_com + 6 * (size_t)node_of(j);
-                const double dist = dist64(nc);
-                passm = __builtin_amdgcn_ballot_w64(!(a.radius[body] + (-nc[4]) + a.collision_th > dist));
-                if (STATS)
-                    n_recheck += 1;
-            }
-            uint64_t okm = mj & passm;
-            if (self_test)  // the body itself has d2 == 0 (the reference skips it by pointer)
-                okm &= __builtin_amdgcn_ballot_w64(d2 > 0.f);
-            if (okm != 0ull) {
-                asm volatile("" ::: "memory");
-                const float sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? force_scale3<MODE>(d2, nm, eps2, eps3) : 0.f;
-                fx = __builtin_fmaf(dx, sc, fx);
-                fy = __builtin_fmaf(dy, sc, fy);
-                fz = __builtin_fmaf(dz, sc, fz);
-            }
-            if (STATS) {
-                n_eval += (unsigned long long)__popcll(mj);
-                n_acc += (unsigned long long)__popcll(okm);
-                n_visit += 1;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        sx += (double)fx;
-        sy += (double)fy;
-        sz += (double)fz;
+    static __device__ __forceinline__ bool has(uint32_t entry, int sib) { return (uint32_t)sib < (entry & 15u); }
+    static __device__ __forceinline__ Aux no_aux() { return make_uint4(0u, 0u, 0u, 0u); }
+    static __device__ __forceinline__ uint32_t wbits(const float4 &, const Aux &x) { return x.x; }
+    static __device__ __forceinline__ float mass(const float4 &r) { return r.w; }
+    static __device__ __forceinline__ Pt<3> point(const float4 &r)
+    {
+        Pt<3> p;
+        p.xy = v2f{r.x, r.y};
+        p.z = r.z;
+        return p;
     }
-
-    if (STATS && lane == 0) {
-        atomicAdd(&a.counters[0], n_eval);
-        atomicAdd(&a.counters[1], n_acc);
-        atomicAdd(&a.counters[4], n_recheck);
-        atomicAdd(&a.counters[5], n_visit);
-        atomicAdd(&a.counters[6], n_batch);
-        atomicMax(&a.counters[7], (unsigned long long)max_top);
+    static __device__ __forceinline__ uint32_t child(const Aux &x) { return x.y; }
+    static __device__ __forceinline__ uint4 stage(uint64_t um, const Aux &x)
+    {
+        return make_uint4((uint32_t)um, (uint32_t)(um >> 32), x.x, x.y);
     }
-    if (!valid)
-        return;
-    double acc[3] = {0.0, 0.0, 0.0};
-    double *ap = a.acc + 3 * (size_t)body;
-    if (dynamic) {
-        acc[0] = sx * a.ia.acc_factor;
-        acc[1] = sy * a.ia.acc_factor;
-        acc[2] = sz * a.ia.acc_factor;
+    static __device__ __forceinline__ float stage_extra(const Aux &x) { return __uint_as_float(x.z); }
+    static __device__ __forceinline__ float staged_width(const float4 &, const uint4 &q) { return __uint_as_float(q.z); }
+    static __device__ __forceinline__ float staged_prune(const uint4 &, const float *extra, int j) { return extra[j]; }
+    static __device__ __forceinline__ uint32_t staged_child(const uint4 &q) { return q.w; }
+    static __device__ __forceinline__ const double *pos_ptr(const Args &a, uint32_t body) { return a.pos + 3 * (size_t)body; }
+    static __device__ __forceinline__ void store_acc(const Args &a, uint32_t body, const double (&acc)[3])
+    {
         for (int d = 0; d < 3; ++d)
-            ap[d] = acc[d];
-    } else {
-        // a static body keeps the acceleration it was given (barnesHut.cpp:96-106)
-        for (int d = 0; d < 3; ++d)
-            acc[d] = ap[d];
+            a.acc[3 * (size_t)body + d] = acc[d];
     }
-    // every body is advanced with its own velocity (barnesHut.cpp:108-123)
-    if (a.ia.do_integrate) {
+    static __device__ __forceinline__ void load_acc(const Args &a, uint32_t body, double (&acc)[3])
+    {
+        for (int d = 0; d < 3; ++d)
+            acc[d] = a.acc[3 * (size_t)body + d];
+    }
+    static __device__ __forceinline__ void integrate(const Args &a, uint32_t body, const double (&acc)[3])
+    {
         for (int d = 0; d < 3; ++d) {
             const double v = a.vel[3 * (size_t)body + d] + acc[d] * a.ia.dt_kick;
             a.vel[3 * (size_t)body + d] = v;
-            a.pos[3 * (size_t)body + d] = pd[d] + v * a.ia.dt;
+            a.pos[3 * (size_t)body + d] = a.pos[3 * (size_t)body + d] + v * a.ia.dt;
         }
     }
+};
+constexpr int TR3_WPB = Traversal<3>::WPB;
+
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(64 * TR3_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bh3_force(Force3Args a)
+{
+    traverse_and_integrate<3, MODE, STATS>(a);
 }
 
 int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
@@ -886,21 +581,21 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     f.collision_th = a.collision_th;
     const int waves = (ntarget + 63) / 64;
     const dim3 grid((waves + TR3_WPB - 1) / TR3_WPB);
-    const int mode = a.fc.exact_denom ? F3_EXACT : (a.fc.eps2_negligible ? F3_NOEPS : F3_EPS);
+    const int mode = a.fc.exact_denom ? FM_EXACT : (a.fc.eps2_negligible ? FM_NOEPS : FM_EPS);
     if (a.collect_stats) {
-        if (mode == F3_EXACT)
-            hipLaunchKernelGGL((k_bh3_force<F3_EXACT, true>), grid, dim3(64 * TR3_WPB), 0, s, f);
-        else if (mode == F3_EPS)
-            hipLaunchKernelGGL((k_bh3_force<F3_EPS, true>), grid, dim3(64 * TR3_WPB), 0, s, f);
+        if (mode == FM_EXACT)
+            hipLaunchKernelGGL((k_bh3_force<FM_EXACT, true>), grid, dim3(64 * TR3_WPB), 0, s, f);
+        else if (mode == FM_EPS)
+            hipLaunchKernelGGL((k_bh3_force<FM_EPS, true>), grid, dim3(64 * TR3_WPB), 0, s, f);
         else
-            hipLaunchKernelGGL((k_bh3_force<F3_NOEPS, true>), grid, dim3(64 * TR3_WPB), 0, s, f);
+            hipLaunchKernelGGL((k_bh3_force<FM_NOEPS, true>), grid, dim3(64 * TR3_WPB), 0, s, f);
     } else {
-        if (mode == F3_EXACT)
-            hipLaunchKernelGGL((k_bh3_force<F3_EXACT, false>), grid, dim3(64 * TR3_WPB), 0, s, f);
-        else if (mode == F3_EPS)
-            hipLaunchKernelGGL((k_bh3_force<F3_EPS, false>), grid, dim3(64 * TR3_WPB), 0, s, f);
+        if (mode == FM_EXACT)
+            hipLaunchKernelGGL((k_bh3_force<FM_EXACT, false>), grid, dim3(64 * TR3_WPB), 0, s, f);
+        else if (mode == FM_EPS)
+            hipLaunchKernelGGL((k_bh3_force<FM_EPS, false>), grid, dim3(64 * TR3_WPB), 0, s, f);
         else
-            hipLaunchKernelGGL((k_bh3_force<F3_NOEPS, false>), grid, dim3(64 * TR3_WPB), 0, s, f);
+            hipLaunchKernelGGL((k_bh3_force<FM_NOEPS, false>), grid, dim3(64 * TR3_WPB), 0, s, f);
     }
     NB_HIP(hipGetLastError());
     return NB_OK;
