@@ -60,8 +60,9 @@ def barrier_sync(world):
 def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=True, params=None, late_at=0,
               cells=False):
     """Returns (seconds for `steps` steps, max over ranks; mean per-stage ms of this rank; traversal
-    counters of rank 0; and, with late_at > 0, the same timing repeated once the run has reached
-    step late_at: {"ms_per_step", "stage_ms", "at_step"})."""
+    counters of rank 0; and, with late_at > 0 (one step number or several), the same timing repeated
+    once the run has reached that step: {"ms_per_step", "stage_ms", "at_step"}, further steps as a
+    list of such entries under "later")."""
     from nbody_amd.distributed import DistributedSim, GpuEngine
 
     sim = nb.NBodySim(len(bodies), alg, params)
@@ -142,9 +143,11 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
         step()  # keep the ranks' collectives matched with rank 0's extra step
     late = None
     done = warmup + steps + (1 if alg == nb.BARNES_HUT else 0)
-    if late_at > done:
+    for at in sorted(a for a in (late_at if isinstance(late_at, (tuple, list)) else (late_at,)) if a > 0):
+        if at <= done:
+            continue
         sim.set_stage_timing(False, counters=False)
-        for _ in range(late_at - done):
+        for _ in range(at - done):
             step()
         sim.set_stage_timing(stage_timing, counters=False)
         barrier_sync(world)
@@ -158,7 +161,12 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
             t = torch.tensor([ldt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ldt = float(t.item())
-        late = {"at_step": late_at, "ms_per_step": ldt * 1e3 / steps, "stage_ms": lstages}
+        done = at + steps
+        entry = {"at_step": at, "ms_per_step": ldt * 1e3 / steps, "stage_ms": lstages}
+        if late is None:
+            late = entry
+        else:
+            late.setdefault("later", []).append(entry)
     barrier_sync(world)  # every rank's last collectives are done before the communicator goes
     sim.close()
     return dt, stages, counters, late
@@ -291,6 +299,9 @@ def main():
     ap.add_argument("--position-exchange", action="store_true",
                     help="N > 1: all-gather the positions every step instead of the cell exchange")
     ap.add_argument("--late-step", type=int, default=300, help="also time the headline run from this step on (0: no)")
+    ap.add_argument("--later-step", type=int, default=620,
+                    help="and once more from this step on (ejected bodies have stretched the box: the tree closes at level 11); "
+                         "0 or --late-step 0: no")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -336,7 +347,8 @@ def main():
     # (all-gather of the positions, whole tree rebuilt on every GPU) is timed beside it.
     cells = world > 1 and not args.position_exchange
     dt, stages, counters, late = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device,
-                                           late_at=args.late_step, cells=cells)
+                                           late_at=(args.late_step, args.later_step if args.late_step > 0 else 0),
+                                           cells=cells)
     ms_per_step = dt * 1e3 / args.steps
     gathered = None
     if cells:
