@@ -283,8 +283,14 @@ int nb_diagnostics(nb_sim *sim, double *out, int count);
  * accelerations the bodies of `sim` (their masses, radii, dynamic flags and parameters) have at the
  * positions pos_xy -- n records {x, y} in device memory, in the order the bodies were given to
  * nb_set_bodies -- written to acc_xy (device memory, n records {ax, ay}, same order; a static body
- * gets the acceleration the handle holds for it, as nb_read_bodies would return).  The handle's own
- * state (positions, velocities, step count) is neither read nor changed.
+ * gets the acceleration the handle holds for it, as nb_read_bodies would return).  Nothing of the
+ * handle is changed, and its positions and velocities are not read; what IS read are the arrays
+ * the handle's own steps rewrite on the handle's stream -- the exchange order (renewed by
+ * nb_refresh_order and every 256 steps by nb_step), the stored accelerations, masses, radii and
+ * dynamic flags.  This call orders nothing between the two streams (an event wait would not be
+ * capturable): when hip_stream is not the handle's stream, call nb_sync after the last nb_step /
+ * nb_refresh_order / nb_set_bodies before calling this, and let this call's work finish before
+ * the next of those.
  *
  * Everything in between (permuted positions, keys, sort buffers, tree, centres of mass, traversal
  * records) lives in one static device array of 40 MiB that every GPU the library runs on holds

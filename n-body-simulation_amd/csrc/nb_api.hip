@@ -331,7 +331,6 @@ static int cells_housekeeping(nb_sim *s, bool *gather)
     *gather = false;
     if (s->exchange == NB_EXCHANGE_POSITIONS || s->cells_checked == s->cells_steps)
         return NB_OK;
-    s->cells_checked = s->cells_steps;
     NB_TRY(pace_wait(s));  // the step CELLS_LAG back has finished: its box is in the ring
     double w = s->cells_box0[0], h = s->cells_box0[1];
     if (s->cells_steps >= CELLS_LAG) {
@@ -342,6 +341,8 @@ static int cells_housekeeping(nb_sim *s, bool *gather)
             return fail(NB_ERR_OVERFLOW, "cell exchange: the bounding box grew by more than a tenth within four steps; "
                                          "a tree was cut above the level it closes at");
     }
+    // (only now: a slot that reports a tree cut short fails every call for this step, not just the first)
+    s->cells_checked = s->cells_steps;
     const int levels = choose_cells_levels(s, CELLS_MARGIN * w, CELLS_MARGIN * h);
     if (levels < 0) {
         *gather = s->cells_active;

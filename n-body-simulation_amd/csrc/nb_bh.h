@@ -65,6 +65,7 @@ struct BhBuffers {
     double *agg = nullptr;            // cell exchange: one record per cell of the keys' last level (bh_cells_alloc)
     double *red4 = nullptr;           // cell exchange: {-min x, max x, -min y, max y} of the own bodies
     uint32_t *err = nullptr;          // (unused device word kept beside them)
+    uint32_t step_hint = 0xffffffffu; // *hint_host as bh_bbox read it for this step's launches
     bool use_pyr = false;             // this step's kernels are launched for the dense-pyramid build ...
     int pyr_levels = -1;              // ... and can do keys of up to this many levels (-1: not launched)
     int pyr_max = 10;                 // the deepest key level the pyramid of these buffers has slots for

@@ -274,6 +274,7 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     // which build this step's kernels are launched for: the dense pyramid when the keys of the last
     // finished step stopped at a level it covers
     const uint32_t hint = (b.pc_range && b.hint_host) ? *(volatile const uint32_t *)b.hint_host : 0xffffffffu;
+    b.step_hint = hint;  // (bh_com sizes its grid by the same reading: the device may update the word in between)
     b.use_pyr = hint <= (uint32_t)b.pyr_max;
     // the deepest key level the pyramid kernels launched for this step can do (k_pyr_mid is only
     // launched when the hint is beyond PYR_MAX_LEVEL; deeper keys than that take the fallback)
@@ -2021,7 +2022,7 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
         // holds the one-block fallback for keys deeper than these launches cover).
         // one block per cell of the split level of the previous steps' keys (blocks go round if this
         // step's keys are deeper)
-        const uint32_t hint = *(volatile const uint32_t *)b.hint_host;
+        const uint32_t hint = b.step_hint;
         const int deepest = (int)(hint <= (uint32_t)b.pyr_max ? hint : (uint32_t)b.pyr_max);
         const dim3 grid(1u << (2 * pyr_split(deepest)));
         hipLaunchKernelGGL(k_pyr_sub<false>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range, (const double *)nullptr);

@@ -325,6 +325,7 @@ int load_bodies(S *s, const typename S::Body *b, int n)
     NB_HIP(hipStreamSynchronize(s->stream));
     NB_TRY(s->after_load());
     s->steps_in_order = 0;
+    s->rb.origin_set = false;  // the box of a renewal of the previous bodies says nothing about these
     return NB_OK;
 }
 
@@ -343,17 +344,22 @@ int host_order(S *s)
 // Renews the exchange order on the device, everything enqueued on the stream (nb_refresh.h): new
 // order from the current positions, every per-body array gathered into it, the direct sum's
 // records packed again.  The float records' origin moves to the middle of the box the PREVIOUS
-// renewal saw (the device leaves it in host-visible memory; the host never waits for it), so a
-// drifting system keeps its precision.
+// renewal saw, so a drifting system keeps its precision.  The device leaves that box in
+// host-visible memory; the host reads it only behind the event recorded after the kernel that wrote
+// it (a renewal is at least 32 steps old by then, so the wait ends at once unless the host has run
+// a whole interval ahead of the device).  Renewal k therefore always takes the box of renewal
+// k - 1, however far ahead the host runs: the same values on every run and on every rank.
 template <class S>
 int device_refresh(S *s)
 {
     constexpr int D = S::D;
     if (s->rb.n != s->n)
         NB_TRY(refresh_alloc(s->rb, s->n));
-    if (s->rb.origin_set && s->alg == NB_ALG_DIRECT)
+    if (s->rb.origin_set && s->alg == NB_ALG_DIRECT) {
+        NB_HIP(hipEventSynchronize(s->rb.box_done));
         for (int d = 0; d < D; ++d)
             s->units.origin[d] = ((volatile double *)s->rb.origin_host)[d];
+    }
     NB_TRY(refresh_sort(s->stream, s->rb, s->pos, D, s->n));
     NB_TRY(refresh_gather(s->stream, s->rb, s->pos, D * sizeof(double), s->n));
     NB_TRY(refresh_gather(s->stream, s->rb, s->vel, D * sizeof(double), s->n));

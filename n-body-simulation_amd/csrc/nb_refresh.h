@@ -22,7 +22,8 @@ struct RefreshBuffers {
     double *box = nullptr;   // lo[3], hi[3]
     void *tmp = nullptr;     // one array's worth of bytes (24 n): gathers go through it
     double *origin_host = nullptr;  // pinned: the middle of the box of the last renewal, written by the device
-    bool origin_set = false;        // a renewal was enqueued since the buffers were made
+    hipEvent_t box_done = nullptr;  // recorded behind the kernel that writes origin_host
+    bool origin_set = false;        // a renewal was enqueued since the bodies were last set
 };
 
 int refresh_alloc(RefreshBuffers &r, int n);

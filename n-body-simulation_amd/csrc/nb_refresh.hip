@@ -172,6 +172,10 @@ int refresh_alloc(RefreshBuffers &r, int n)
     if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
         return fail(NB_ERR_NOMEM, "hipHostMalloc failed");
     r.origin_host = (double *)h;
+    for (int d = 0; d < 8; ++d)
+        r.origin_host[d] = 0.0;
+    if (hipEventCreateWithFlags(&r.box_done, hipEventDisableTiming) != hipSuccess)
+        return fail(NB_ERR_HIP, "hipEventCreate failed");
     r.origin_set = false;
     return NB_OK;
 }
@@ -190,6 +194,8 @@ void refresh_free(RefreshBuffers &r)
     (void)hipFree(r.tmp);
     if (r.origin_host)
         (void)hipHostFree(r.origin_host);
+    if (r.box_done)
+        (void)hipEventDestroy(r.box_done);
     r = RefreshBuffers();
 }
 
@@ -211,6 +217,7 @@ int refresh_sort(hipStream_t s, RefreshBuffers &r, const double *pos, int dims, 
         hipLaunchKernelGGL(k_rf_keys<3>, grid, dim3(256), 0, s, pos, n, r.box, r.keys[0], r.idx[0]);
     }
     NB_HIP(hipGetLastError());
+    NB_HIP(hipEventRecord(r.box_done, s));  // the box kernel is the second of the three: origin_host is written by then
     r.origin_set = true;
     return sort_pairs(s, r.keys, r.idx, n, r.cut, r.hist, r.totals, 4);  // passes 4..7 (k_rf_box's cut[2]); result in buffer 0
 }

@@ -252,6 +252,16 @@ int main(int argc, char **argv)
             } else
                 kids.push_back(pid);
         }
+        // Every process keeps only the pipe ends it uses, so that a rank whose writer has gone
+        // sees end-of-file instead of waiting for ever: the parent none, rank 0 the write ends,
+        // rank r its own read end.
+        for (int r = 1; r < gpus; ++r) {
+            const bool keep_read = child && rank == r, keep_write = child && rank == 0;
+            if (!keep_read)
+                close(fds[2 * (size_t)r]);
+            if (!keep_write)
+                close(fds[2 * (size_t)r + 1]);
+        }
         if (!child) {
             int failed = 0;
             for (pid_t pid : kids) {
@@ -272,15 +282,29 @@ int main(int argc, char **argv)
             return EXIT_FAILURE;
         }
         if (rank == 0) {
+            // (a failure in here ends rank 0, which closes its write ends: the other ranks read
+            // end-of-file and exit non-zero)
             nbody::check(nb_comm_unique_id(comm_id, sizeof(comm_id)), "nb_comm_unique_id");
-            for (int r = 1; r < gpus; ++r)
+            for (int r = 1; r < gpus; ++r) {
                 if (write(fds[2 * (size_t)r + 1], comm_id, sizeof(comm_id)) != (ssize_t)sizeof(comm_id)) {
                     std::perror("write");
                     return EXIT_FAILURE;
                 }
-        } else if (read(fds[2 * (size_t)rank], comm_id, sizeof(comm_id)) != (ssize_t)sizeof(comm_id)) {
-            std::perror("read");
-            return EXIT_FAILURE;
+                close(fds[2 * (size_t)r + 1]);
+            }
+        } else {
+            size_t got = 0;
+            while (got < sizeof(comm_id)) {
+                const ssize_t k = read(fds[2 * (size_t)rank], comm_id + got, sizeof(comm_id) - got);
+                if (k <= 0)
+                    break;  // end-of-file (rank 0 failed before it wrote) or an error
+                got += (size_t)k;
+            }
+            close(fds[2 * (size_t)rank]);
+            if (got != sizeof(comm_id)) {
+                std::cerr << "rank " << rank << ": rank 0 ended before it sent the communicator id" << std::endl;
+                return EXIT_FAILURE;
+            }
         }
         quiet = quiet || rank != 0;
     }

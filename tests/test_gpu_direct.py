@@ -325,6 +325,40 @@ def test_long_direct_run_refreshes_by_itself(nb, oracle):
     assert np.abs(got["pos"] - want["pos"]).max() / np.abs(want["pos"]).max() < 1e-4
 
 
+def test_new_bodies_forget_the_previous_systems_box(nb, oracle):
+    """The float records' origin follows the box of the renewal before the last one.  A handle that
+    ran system A past two renewals and is then given a far-away system B must treat B exactly as a
+    fresh handle does: the same bits, also when many steps with renewals are enqueued at once (the
+    origin a renewal takes does not depend on how far the host runs ahead of the device)."""
+    n = 4096
+    a0 = oracle.scenario(0, n, 21)
+    b0 = oracle.scenario(0, n, 22)
+    b0["pos"] += np.array([6.0e13, -4.0e13])  # 60 times the system's size away
+    used = nb.NBodySim(n, nb.DIRECT)
+    used.set_bodies(a0)
+    for _ in range(3):
+        used.update(2)
+        used.refresh_order()
+    fresh = nb.NBodySim(n, nb.DIRECT)
+    outs = []
+    for sim in (used, fresh):
+        sim.set_bodies(b0)
+        for _ in range(3):
+            sim.update(2)
+            sim.refresh_order()
+        sim.update(1)
+        outs.append(sim.read_bodies())
+        sim.close()
+    for f in ("pos", "vel", "acc"):
+        assert np.array_equal(outs[0][f], outs[1][f]), f
+    want = oracle.direct_step(b0, 7)
+    ext = np.abs(want["pos"] - want["pos"].mean(0)).max()
+    assert np.abs(outs[0]["pos"] - want["pos"]).max() / ext < 1e-6
+    # accelerations at the state six steps on keep the bar although the system sits far from the origin
+    six = oracle.direct_step(b0, 6)
+    assert rel_err(outs[0]["acc"], oracle.direct_accel(six)).max() <= ACC_TOL
+
+
 def test_full_size_direct_properties(nb, oracle):
     """The N = 1,000,000 direct-sum configuration itself: sampled targets against the oracle, and
     Newton's third law over all bodies (the pair rule is symmetric, so sum m a vanishes up to the

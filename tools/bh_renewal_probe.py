@@ -1,9 +1,10 @@
 """Average step time of the collision workload (N = 5M, Barnes-Hut) over 512 steps with the exchange
 order renewed by hand every `every` steps, beside the library's own schedule (tuning aid)."""
+import os
 import sys
 import time
 
-sys.path.insert(0, __file__.rsplit("/", 1)[0])
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_package  # noqa: E402
 
 nb = load_package()

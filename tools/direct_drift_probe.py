@@ -1,9 +1,10 @@
 """Throughput of the direct sum at N = 65536 along a run, with the library's own order renewal and
 with one forced every `every` steps (tuning aid, run by hand)."""
+import os
 import sys
 import time
 
-sys.path.insert(0, __file__.rsplit("/", 1)[0])
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_package  # noqa: E402
 
 nb = load_package()

@@ -1,11 +1,12 @@
 """Stage times of the collision workload (N = 5M, Barnes-Hut) every 16 steps, and what a renewal of
 the exchange order costs and gains (tuning aid, run by hand)."""
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, __file__.rsplit("/", 1)[0])
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_package  # noqa: E402
 
 nb = load_package()

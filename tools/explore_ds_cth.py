@@ -1,8 +1,9 @@
 """Direct-sum rate at small N over a longer run, in chunks of steps (tuning aid, not a test)."""
+import os
 import sys
 import time
 
-sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_package  # noqa: E402
 
 nb = load_package()

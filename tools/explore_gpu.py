@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import bodies_from_golden, golden, load_package, rel_err  # noqa: E402
 from oracle_lib import Oracle  # noqa: E402
 

@@ -2,7 +2,7 @@
 timed in blocks, then once more after nb_refresh_order.  Measured: 0.60 -> 0.80 ms/step as the disc spreads
 (deeper tree); re-deriving the exchange order changes nothing, i.e. the order is not what costs time."""
 import os, sys, time
-sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_package
 nb = load_package()
 n = 1000000

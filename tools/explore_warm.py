@@ -1,10 +1,11 @@
 """Does the order of the bodies inside the closed leaves matter?  (tuning aid, not a test)
 The headline workload after 300 steps, timed before and after nb_refresh_order, which re-sorts the
 exchange order -- the order the stable sort keeps inside a leaf -- by the current positions."""
+import os
 import sys
 import time
 
-sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_package  # noqa: E402
 
 nb = load_package()

@@ -1,6 +1,6 @@
 """Randomised parity sweep against the CPU oracle (not collected by pytest; run by hand on a GPU box):
 
-    python tests/fuzz_parity.py [cases] [seed] [big]
+    python tools/fuzz_parity.py [cases] [seed] [big]
 
 ("big": sizes 8 000 .. 50 000 instead of 2 .. 3001; the oracle's direct sum then takes seconds per case.)
 
@@ -14,7 +14,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_package, rel_err  # noqa: E402
 from oracle_lib import Oracle  # noqa: E402
 

@@ -1,9 +1,10 @@
 """Runs the collision workload (N = 5M, Barnes-Hut) to a late step and times it there (tuning aid,
 run by hand; `trace` = only run, for a kernel trace of the last steps)."""
+import os
 import sys
 import time
 
-sys.path.insert(0, __file__.rsplit("/", 1)[0])
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_package  # noqa: E402
 
 nb = load_package()

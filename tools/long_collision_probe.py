@@ -2,12 +2,13 @@
 times, the level the keys stop at and whether the state stays finite (tuning aid, run by hand).
 The box keeps growing with the ejected bodies: the tree closes at level 8 at the start, 11 from
 step ~400, deeper later -- every hand-over between the builds lies on this path."""
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, __file__.rsplit("/", 1)[0])
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_package  # noqa: E402
 
 nb = load_package()

@@ -1,10 +1,11 @@
 """Traversal counters and stage times of the collision workload at a late step (tuning aid)."""
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, __file__.rsplit("/", 1)[0])
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_package  # noqa: E402
 
 nb = load_package()
