@@ -62,6 +62,9 @@ struct BhBuffers {
     int launched = 0;                 // levels the per-level build kernels were launched for
     uint2 *pc_range = nullptr;        // dense pyramid: first and one-past-last sorted body of every cell of the
                                       // keys' last level (both zero: empty cell); null: no pyramid
+    uint2 *gl_hdr = nullptr;          // traversal: interaction lists per group of waves (nb_traverse.h GroupLists);
+    float4 *gl_far = nullptr;         //   null: none (buffers carved from a caller's arena), every wave starts
+    uint32_t *gl_seed = nullptr;      //   at the root
     double *agg = nullptr;            // cell exchange: one record per cell of the keys' last level (bh_cells_alloc)
     double *red4 = nullptr;           // cell exchange: {-min x, max x, -min y, max y} of the own bodies
     uint32_t *err = nullptr;          // (unused device word kept beside them)

@@ -31,6 +31,7 @@
 static int g_threads = 1;
 
 void orc_set_threads(int threads) { g_threads = threads < 1 ? 1 : threads; }
+int orc_get_threads(void) { return g_threads; }
 
 void orc_default_params(orc_params *p)
 {
@@ -624,7 +625,8 @@ static void gt_force(const orc_params *p, const gtree *t, int ni, const orc_body
     }
 }
 
-void orc_bh_gpu_accel(const orc_params *p, int n, const orc_body *b, int depth, double *acc)
+/* The accelerations of the bodies targets[0..nt) (NULL: body k) from the tree of all n bodies. */
+void orc_bh_gpu_accel_list(const orc_params *p, int n, const orc_body *b, int depth, int nt, const int *targets, double *acc)
 {
     double box[4];
     orc_bh_gpu_bbox(p, n, b, box);
@@ -634,17 +636,24 @@ void orc_bh_gpu_accel(const orc_params *p, int n, const orc_body *b, int depth, 
         ids[i] = i;
     gt_build(&t, b, ids, n, box[0], box[1], box[2], box[3], 0, depth);
     const double width = box[2] - box[0];
-    for (int i = 0; i < n; ++i) {
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads) if (g_threads > 1)
+    for (int k = 0; k < nt; ++k) {
+        const int i = targets ? targets[k] : k;
         double ax = b[i].ax, ay = b[i].ay;
         if (b[i].is_dynamic) {
             ax = ay = 0.0;
             gt_force(p, &t, 0, &b[i], width, &ax, &ay);
         }
-        acc[2 * i] = ax;
-        acc[2 * i + 1] = ay;
+        acc[2 * k] = ax;
+        acc[2 * k + 1] = ay;
     }
     free(ids);
     free(t.nd);
+}
+
+void orc_bh_gpu_accel(const orc_params *p, int n, const orc_body *b, int depth, double *acc)
+{
+    orc_bh_gpu_accel_list(p, n, b, depth, n, NULL, acc);
 }
 
 void orc_bh_gpu_step(const orc_params *p, int n, orc_body *b, int depth, int nsteps)

@@ -36,6 +36,7 @@ void orc_default_params(orc_params *p);
 /* Threads for the per-target loops of the *_accel functions (default 1, the reference's own
  * single thread).  Results are independent of it. */
 void orc_set_threads(int threads);
+int orc_get_threads(void);
 
 /* Scenarios 0 spiral, 1 random, 2 collision, 3 solar (GPU-BH numbering). */
 int orc_init_scenario(int sim, int n, unsigned seed, orc_body *out);
@@ -72,6 +73,8 @@ int orc_bh_step(const orc_params *p, int n, orc_body *b, int nsteps);
  * (it cannot be built here): parity unpinned. */
 void orc_bh_gpu_bbox(const orc_params *p, int n, const orc_body *b, double *box);
 void orc_bh_gpu_accel(const orc_params *p, int n, const orc_body *b, int depth, double *acc);
+/* ... of the bodies targets[0..nt) only (the tree is that of all n bodies); acc: nt records. */
+void orc_bh_gpu_accel_list(const orc_params *p, int n, const orc_body *b, int depth, int nt, const int *targets, double *acc);
 /* nsteps of the GPU program's update (only dynamic bodies are advanced, :431-443). */
 void orc_bh_gpu_step(const orc_params *p, int n, orc_body *b, int depth, int nsteps);
 
@@ -108,6 +111,10 @@ void orc3_direct_step(const orc_params *p, int n, orc3_body *b, int nsteps);
 void orc3_bh_bbox(const orc_params *p, int n, const orc3_body *b, double *box);
 /* stats as orc_bh_accel; acc = 3 doubles per body. */
 int orc3_bh_accel(const orc_params *p, int n, const orc3_body *b, double *acc, double *stats);
+/* ... of the bodies targets[0..nt) only, from the octree of all n bodies (inserted in the sequence
+ * order[0..n) when given: same tree, faster build); acc: nt records of 3 doubles. */
+int orc3_bh_accel_list(const orc_params *p, int n, const orc3_body *b, const int *order, int nt, const int *targets,
+                       double *acc, double *stats);
 int orc3_bh_step(const orc_params *p, int n, orc3_body *b, int nsteps);
 /* Octant path of each body, 20 levels: the digit of level l sits in bits [61-3l, 59-3l] and is
  * 4*(below the z midpoint) + 2*(below the y midpoint) + (right of the x midpoint). */

@@ -303,7 +303,11 @@ static void ot_force(trav3 *tv, int ni, int body)
         ot_force(tv, q->child[c], body);
 }
 
-int orc3_bh_accel(const orc_params *p, int n, const orc3_body *b, double *acc, double *stats)
+/* The accelerations of the bodies targets[0..nt) (NULL: body k) from the octree of all n bodies,
+ * which is built once.  order (may be NULL) gives the sequence in which the bodies are inserted:
+ * the one-body-per-leaf tree does not depend on it, only the time the insertions take does. */
+int orc3_bh_accel_list(const orc_params *p, int n, const orc3_body *b, const int *order, int nt, const int *targets,
+                       double *acc, double *stats)
 {
     double box[6];
     orc3_bh_bbox(p, n, b, box);
@@ -311,37 +315,47 @@ int orc3_bh_accel(const orc_params *p, int n, const orc3_body *b, double *acc, d
     memset(&t, 0, sizeof(t));
     int root = ot_new(&t, box[0], box[1], box[2], box[3], box[4], box[5]);
     for (int i = 0; i < n; ++i)
-        ot_insert(&t, root, b, i, 0);
+        ot_insert(&t, root, b, order ? order[i] : i, 0);
     if (t.failed) {
         free(t.nd);
         return -1;
     }
     ot_center_mass(&t, root, b);
-    trav3 tv;
-    tv.p = p;
-    tv.b = b;
-    tv.t = &t;
-    tv.eps2 = p->eps * p->eps;
-    tv.visits = tv.accepted = 0;
-    for (int i = 0; i < n; ++i) {
+    double nv = 0.0, na = 0.0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : nv, na) num_threads(orc_get_threads()) if (orc_get_threads() > 1)
+    for (int j = 0; j < nt; ++j) {
+        const int i = targets ? targets[j] : j;
         if (b[i].is_dynamic) {
+            trav3 tv;
+            tv.p = p;
+            tv.b = b;
+            tv.t = &t;
+            tv.eps2 = p->eps * p->eps;
+            tv.visits = tv.accepted = 0;
             tv.a[0] = tv.a[1] = tv.a[2] = 0.0;
             ot_force(&tv, root, i);
             for (int k = 0; k < 3; ++k)
-                acc[3 * i + k] = tv.a[k];
+                acc[3 * j + k] = tv.a[k];
+            nv += tv.visits;
+            na += tv.accepted;
         } else {
             for (int k = 0; k < 3; ++k)
-                acc[3 * i + k] = b[i].a[k];
+                acc[3 * j + k] = b[i].a[k];
         }
     }
     if (stats) {
-        stats[0] = tv.visits;
-        stats[1] = tv.accepted;
+        stats[0] = nv;
+        stats[1] = na;
         stats[2] = t.max_depth;
         stats[3] = t.count;
     }
     free(t.nd);
     return 0;
+}
+
+int orc3_bh_accel(const orc_params *p, int n, const orc3_body *b, double *acc, double *stats)
+{
+    return orc3_bh_accel_list(p, n, b, NULL, n, NULL, acc, stats);
 }
 
 int orc3_bh_step(const orc_params *p, int n, orc3_body *b, int nsteps)

@@ -73,3 +73,22 @@ def rel_err(a, ref):
     out[nz] = num[nz] / den[nz]
     out[~nz & (num > 0)] = np.inf
     return out
+
+
+def sampled_targets(b, count, seed):
+    """`count` dynamic bodies: half drawn uniformly, half the ones nearest to the most massive
+    bodies (the densest part of the tree, where cells close to the cutoff are judged)."""
+    rng = np.random.default_rng(seed)
+    n = len(b)
+    dyn = np.flatnonzero(b["is_dynamic"] != 0)
+    picks = set(int(v) for v in rng.choice(dyn, count // 2, replace=False))
+    suns = np.argsort(b["mass"])[-2:]
+    for s_ in suns:
+        d = np.linalg.norm(b["pos"] - b["pos"][s_], axis=1)
+        d[b["is_dynamic"] == 0] = np.inf
+        for v in np.argsort(d)[: count // 4 + 2]:
+            if len(picks) < count:
+                picks.add(int(v))
+    while len(picks) < count:
+        picks.add(int(rng.choice(dyn)))
+    return np.sort(np.fromiter(picks, dtype=np.int64)).astype(np.int32)

@@ -90,6 +90,10 @@ class Oracle:
         L.orc_bh_gpu_bbox.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p]
         L.orc_bh_gpu_accel.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_bh_gpu_step.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_bh_gpu_accel_list.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc3_bh_accel_list.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]
+        L.orc3_bh_accel_list.restype = C.c_int
         L.orc3_init_scenario.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_double, C.c_void_p]
         L.orc3_init_scenario.restype = C.c_int
         L.orc3_direct_accel.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -195,6 +199,14 @@ class Oracle:
         self.lib.orc_bh_gpu_accel(C.byref(p), len(b), _ptr(b), depth, _ptr(acc))
         return acc
 
+    def gpu_accel_list(self, b, targets, depth=9, p=None):
+        """The GPU program's tree of all bodies, walked for the listed bodies only."""
+        p = p or self.params()
+        t = np.ascontiguousarray(targets, dtype=np.int32)
+        acc = np.zeros((len(t), 2))
+        self.lib.orc_bh_gpu_accel_list(C.byref(p), len(b), _ptr(b), depth, len(t), _ptr(t), _ptr(acc))
+        return acc
+
     def gpu_step(self, b, nsteps, depth=9, p=None):
         p = p or self.params()
         b = b.copy()
@@ -234,6 +246,24 @@ class Oracle:
         acc = np.zeros((len(b), 3))
         stats = np.zeros(4)
         if self.lib.orc3_bh_accel(C.byref(p), len(b), _ptr(b), _ptr(acc), _ptr(stats)) != 0:
+            raise ValueError("coincident bodies")
+        return (acc, stats) if with_stats else acc
+
+    def bh_accel_list3(self, b, targets, p=None, sorted_insert=True, with_stats=False):
+        """Octree accelerations of the listed bodies only, from the tree of all bodies (inserted in
+        the order of their octant paths: same tree, built faster)."""
+        p = p or self.params()
+        t = np.ascontiguousarray(targets, dtype=np.int32)
+        order = None
+        if sorted_insert:
+            keys = self.morton_keys3(b, self.bh_bbox3(b, p))
+            order = np.ascontiguousarray(np.argsort(keys, kind="stable"), dtype=np.int32)
+            del keys
+        acc = np.zeros((len(t), 3))
+        stats = np.zeros(4)
+        rc = self.lib.orc3_bh_accel_list(C.byref(p), len(b), _ptr(b), _ptr(order) if order is not None else None,
+                                         len(t), _ptr(t), _ptr(acc), _ptr(stats))
+        if rc != 0:
             raise ValueError("coincident bodies")
         return (acc, stats) if with_stats else acc
 

@@ -10,7 +10,7 @@ system's extent.
 import numpy as np
 import pytest
 
-from conftest import bodies_from_golden, golden, rel_err
+from conftest import sampled_targets, bodies_from_golden, golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -469,25 +469,6 @@ def test_closed_level_edge_cases(nb, oracle, case):
     assert np.all(np.abs(acc[dyn] - ref[dyn]) <= tol * np.maximum(np.linalg.norm(ref[dyn], axis=1, keepdims=True), 1e-12 * scale) + 1e-30)
 
 
-def sampled_targets(b, count, seed):
-    """`count` dynamic bodies: half drawn uniformly, half the ones nearest to the most massive
-    bodies (the densest part of the tree, where cells close to the cutoff are judged)."""
-    rng = np.random.default_rng(seed)
-    n = len(b)
-    dyn = np.flatnonzero(b["is_dynamic"] != 0)
-    picks = set(int(v) for v in rng.choice(dyn, count // 2, replace=False))
-    suns = np.argsort(b["mass"])[-2:]
-    for s_ in suns:
-        d = np.linalg.norm(b["pos"] - b["pos"][s_], axis=1)
-        d[b["is_dynamic"] == 0] = np.inf
-        for v in np.argsort(d)[: count // 4 + 2]:
-            if len(picks) < count:
-                picks.add(int(v))
-    while len(picks) < count:
-        picks.add(int(rng.choice(dyn)))
-    return np.sort(np.fromiter(picks, dtype=np.int64)).astype(np.int32)
-
-
 def test_full_size_collision_matches_the_reference_tree(nb, oracle):
     """The headline workload itself (galaxy collision, N = 5,000,000, theta = 0.5): 512 sampled
     bodies against the oracle's reference-exact tree of all 5 M bodies (built once, walked for the
@@ -518,6 +499,48 @@ def test_full_size_collision_matches_the_reference_tree(nb, oracle):
     ref2 = oracle.bh_accel_list(out, targets)
     err2 = rel_err(acc2[targets], ref2)
     assert err2.max() <= ACC_EXPECTED, err2.max()
+
+
+@pytest.mark.timeout(600)
+def test_late_states_of_the_collision_run_match_the_reference_tree(nb, oracle, capsys):
+    """The headline workload far into its run, where the benchmark times it again: after 300 and
+    after 620 steps of nb_step the discs have collapsed into dense cores (single cells of the
+    closed level hold thousands of bodies), ejected bodies have stretched the box so that the
+    tree closes two to three levels deeper than at the start, and the device has renewed the
+    exchange order by itself (step 256, step 512).  At both states the accelerations of 256
+    sampled bodies (half of them the ones nearest the two suns) are compared with the oracle's
+    reference-exact tree of the state the library holds (calculateForceHelper,
+    src/cpu/barnesHut.cpp:50-89), bar 1e-4; the dense pyramid must have built both trees."""
+    n = 5000000
+    b = nb.init_scenario(nb.COLLISION, n, 12345)
+    seen = []
+    with nb.NBodySim(n, nb.BARNES_HUT) as sim:
+        sim.set_bodies(b)
+        done = 0
+        for upto in (300, 620):
+            sim.update(upto - done)
+            done = upto
+            state = sim.read_bodies()
+            acc = sim.compute_accel()
+            closed, levels = (int(v) for v in sim.debug(nb.DBG_KEY_LEVELS, np.uint32, 2))
+            cnt = sim.debug(nb.DBG_COUNTERS, np.uint64, 8)
+            seen.append((upto, state, acc, closed, levels, int(cnt[2])))
+    for upto, state, acc, closed, levels, nodes in seen:
+        assert np.all(np.isfinite(acc)) and np.all(np.isfinite(state["pos"]))
+        targets = sampled_targets(state, 256, upto)
+        ref, stats = oracle.bh_accel_list(state, targets, with_stats=True)
+        err = rel_err(acc[targets], ref)
+        with capsys.disabled():
+            print("\n[collision 5M, step %d: keys of %d levels (closed %d), %d nodes, oracle depth %d, max err %.2e]"
+                  % (upto, levels, closed, nodes, stats[2], err.max()), flush=True)
+        assert err.max() <= ACC_TOL, (upto, err.max())
+        assert err.max() <= ACC_EXPECTED, (upto, err.max())  # identical decisions leave float rounding only
+        # every cell of levels 0..levels is a node slot: the dense pyramid built this tree
+        assert nodes == (4 ** (levels + 1) - 1) // 3, (upto, levels, nodes)
+        if upto == 300:
+            assert 9 <= levels <= 11, levels
+        else:
+            assert closed == 11 and levels == 11, (closed, levels)
 
 
 @pytest.mark.timeout(600)

@@ -8,7 +8,7 @@ restatement of that program's kernels.
 import numpy as np
 import pytest
 
-from conftest import bodies_from_golden, golden, rel_err
+from conftest import bodies_from_golden, golden, rel_err, sampled_targets
 
 pytestmark = pytest.mark.gpu
 
@@ -66,6 +66,29 @@ def test_trajectory_and_static_bodies(nb, oracle):
     assert np.array_equal(got["pos"][-1], b["pos"][-1])
     scale = np.abs(want["pos"]).max()
     assert np.abs(got["pos"] - want["pos"]).max() / scale < 1.0e-6
+
+
+@pytest.mark.timeout(600)
+def test_full_size_bucket_tree_matches_the_restatement(nb, oracle, capsys):
+    """The size the benchmark times this mode at (galaxy collision, N = 5,000,000, depth 9: buckets of
+    about 19 bodies on average, thousands in the discs' middles, each acting as one point mass --
+    barnesHut_kernel.cu:309,387-399): 256 sampled bodies against the restatement's tree of all
+    bodies, at the start and three steps on."""
+    n = 5000000
+    b = nb.init_scenario(nb.COLLISION, n, 12345)
+    sim, acc = run(nb, b, 9)
+    sim.update(3)
+    later = sim.read_bodies()
+    acc3 = sim.compute_accel()
+    sim.close()
+    for state, got, seed in ((b, acc, 23), (later, acc3, 29)):
+        assert np.all(np.isfinite(got))
+        targets = sampled_targets(state, 256, seed)
+        ref = oracle.gpu_accel_list(state, targets, 9)
+        err = rel_err(got[targets], ref)
+        with capsys.disabled():
+            print("\n[bucket tree 5M: max err %.2e]" % err.max(), flush=True)
+        assert err.max() <= ACC_TOL, err.max()
 
 
 def test_bad_depth_is_rejected(nb):

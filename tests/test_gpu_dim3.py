@@ -10,7 +10,7 @@ Bars as in 2-D: direct sum 1e-5, Barnes-Hut 1e-4 relative per body; FP64 integra
 import numpy as np
 import pytest
 
-from conftest import bodies_from_golden, golden, rel_err
+from conftest import bodies_from_golden, golden, rel_err, sampled_targets
 from oracle_lib import lift3
 
 pytestmark = pytest.mark.gpu
@@ -252,6 +252,25 @@ def test_large_bh3_against_direct3(nb, oracle):
         s.set_bodies(b)
         tight = s.compute_accel()
     assert np.median(rel_err(tight, a_ds)) < np.median(err) / 3
+
+
+@pytest.mark.timeout(600)
+def test_full_size_collision3_matches_the_oracle_octree(nb, oracle, capsys):
+    """The 3-D workload the benchmark times (collision discs, N = 5,000,000, half-thickness 2e10 m):
+    256 sampled bodies (half of them the ones nearest the two suns) against the oracle's octree of
+    all 5 M bodies, built once and walked for the sampled bodies only; bar 1e-4."""
+    n = 5000000
+    b = nb.init_scenario3(nb.COLLISION, n, 12345, thickness=2.0e10)
+    acc = gpu_accel3(nb, b, nb.BARNES_HUT)
+    assert np.all(np.isfinite(acc))
+    targets = sampled_targets(b, 256, 17)
+    ref, stats = oracle.bh_accel_list3(b, targets, with_stats=True)
+    err = rel_err(acc[targets], ref)
+    with capsys.disabled():
+        print("\n[3-D collision 5M: oracle octree of %d nodes, depth %d, %.0f accepted per body, max err %.2e]"
+              % (stats[3], stats[2], stats[1] / len(targets), err.max()), flush=True)
+    assert err.max() <= BH_TOL, err.max()
+    assert err.max() <= 5.0e-6, err.max()  # identical decisions leave float rounding only
 
 
 @pytest.mark.parametrize("alg", [0, 1])

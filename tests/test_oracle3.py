@@ -88,3 +88,22 @@ def test_bh3_tends_to_direct3_as_theta_shrinks(oracle):
     # cutoff rule (> against >=) and the order of the additions
     a0 = oracle.bh_accel3(b, oracle.params(theta=0.0))[dyn]
     assert (np.linalg.norm(a0 - ref, axis=1) / np.linalg.norm(ref, axis=1)).max() < 1e-12
+
+
+def test_target_lists_equal_the_full_walks(oracle):
+    """The list variants the full-size GPU tests use (one tree of all bodies, walked for sampled
+    bodies only, any thread count, any insertion order) return the full walks' values bit for bit:
+    the octree, and the 2-D tree of the reference's GPU program."""
+    b3 = oracle.scenario3(2, 3000, 9, thickness=2.0e10)
+    full = oracle.bh_accel3(b3)
+    targets = np.sort(np.random.default_rng(1).choice(len(b3), 200, replace=False)).astype(np.int32)
+    for threads, sorted_insert in ((1, False), (4, True)):
+        oracle.set_threads(threads)
+        got = oracle.bh_accel_list3(b3, targets, sorted_insert=sorted_insert)
+        assert np.array_equal(got, full[targets])
+    b2 = oracle.scenario(2, 3000, 9)
+    full2 = oracle.gpu_accel(b2, depth=5)
+    got2 = oracle.gpu_accel_list(b2, targets, depth=5)
+    oracle.set_threads(1)
+    assert np.array_equal(got2, full2[targets])
+    assert np.array_equal(oracle.gpu_accel_list(b2, targets, depth=5), full2[targets])
