@@ -2145,6 +2145,7 @@ struct Traversal<2> {
         return p;
     }
     static __device__ __forceinline__ uint32_t child(const Aux &x) { return x.x; }
+    static __device__ __forceinline__ uint32_t prune(const Aux &x) { return x.y; }
     static __device__ __forceinline__ uint4 stage(uint64_t um, const Aux &x)
     {
         return make_uint4((uint32_t)um, (uint32_t)(um >> 32), x.x, x.y);
@@ -2285,6 +2286,7 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     dim3 grid((waves + TR_WPB - 1) / TR_WPB);
     if (ntarget <= 0)
         return NB_OK;
+#ifndef NB_TR_LISTS_OFF  // (tuning aid: every wave walks from the root)
     if (b.gl_hdr) {
         // the far tree is walked once per group of waves (nb_traverse.h)
         f.gl.hdr = b.gl_hdr;
@@ -2296,6 +2298,7 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
         else
             hipLaunchKernelGGL(k_bh_lists<false>, lgrid, dim3(64), 0, s, f);
     }
+#endif
     const int mode = a.fc.exact_denom ? FM_EXACT : (a.fc.eps2_negligible ? FM_NOEPS : FM_EPS);
     if (a.collect_stats) {
         if (mode == FM_EXACT)

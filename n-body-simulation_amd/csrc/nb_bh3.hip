@@ -512,6 +512,7 @@ struct Traversal<3> {
         return p;
     }
     static __device__ __forceinline__ uint32_t child(const Aux &x) { return x.y; }
+    static __device__ __forceinline__ uint32_t prune(const Aux &x) { return x.z; }
     static __device__ __forceinline__ uint4 stage(uint64_t um, const Aux &x)
     {
         return make_uint4((uint32_t)um, (uint32_t)(um >> 32), x.x, x.y);

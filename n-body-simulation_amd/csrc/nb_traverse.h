@@ -20,7 +20,8 @@
 //   has(entry, sib)              whether sibling `sib` of a stack entry exists
 //   wbits(rec, aux)              float bits of (width / theta)^2 of a cell; sign bit set for a body: -(r_j + th)
 //   mass(rec), point(rec)        record fields
-//   child(aux), prune(aux)       child word (first child << 4 | ...) and prune threshold bits
+//   child(aux), prune(aux)       child word (first child << 4 | ...; low four bits zero: no children) and the
+//                                float bits of the prune threshold (collision_th - cell diagonal)^2, or -1
 //   stage / staged accessors     what goes into the second staged word and how it is read back
 //   pos_ptr / load_acc / ...     FP64 state layout
 //   LISTS                        whether the waves of a group share interaction lists (GroupLists below);
@@ -171,7 +172,7 @@ __device__ __forceinline__ void build_group_lists(const typename Traversal<DIM>:
     if ((size_t)group * (64 * LIST_WAVES) >= (size_t)ntarget)
         return;
     // bounding box of the group's targets, their largest cell cutoff, and whether any is dynamic
-    float g0[DIM], g1[DIM], safe2 = 0.f;
+    float g0[DIM], g1[DIM], safe2 = 0.f, in2 = __builtin_inff(), ri_min = __builtin_inff();
     bool any_dynamic = false;
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
@@ -190,6 +191,8 @@ __device__ __forceinline__ void build_group_lists(const typename Traversal<DIM>:
         T::load_target(a, k, body, xi, ri);
         const float thn = 2.f * ri + a.fc.cth;
         safe2 = fmaxf(safe2, thn * thn);
+        in2 = fminf(in2, thn * thn);
+        ri_min = fminf(ri_min, ri);
         any_dynamic = any_dynamic || (valid && a.dyn[body]);
 #pragma unroll
         for (int d = 0; d < DIM; ++d) {
@@ -205,8 +208,11 @@ __device__ __forceinline__ void build_group_lists(const typename Traversal<DIM>:
             g1[d] = fmaxf(g1[d], __shfl_xor(g1[d], o));
         }
         safe2 = fmaxf(safe2, __shfl_xor(safe2, o));
+        in2 = fminf(in2, __shfl_xor(in2, o));
+        ri_min = fminf(ri_min, __shfl_xor(ri_min, o));
     }
     safe2 *= 1.001f;
+    in2 *= 0.999f;
     float4 *far = a.gl.far + (size_t)group * LIST_FAR_CAP;
     uint32_t *seed = a.gl.seed + (size_t)group * LIST_SEED_CAP;
     int nfar = 0, nseed = 0, top = 0;
@@ -256,9 +262,16 @@ __device__ __forceinline__ void build_group_lists(const typename Traversal<DIM>:
                 dmax2 = __builtin_fmaf(f, f, dmax2);
             }
         }
-        const uint64_t bodym = __builtin_amdgcn_ballot_w64((int)wb < 0) & cmask;
-        const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~bodym;
-        const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < nw * 0.999f) & farm_all;
+        const uint64_t allbodym = __builtin_amdgcn_ballot_w64((int)wb < 0) & cmask;
+        float none2;  // (see traverse_and_integrate: nodes no body of the box gets anything from)
+        {
+            const float tb = ri_min - nw;
+            const float inside = (T::child(aux) & 15u) != 0u ? __uint_as_float(T::prune(aux)) : in2;
+            none2 = (int)wb < 0 ? tb * tb : inside;
+        }
+        const uint64_t nonem = __builtin_amdgcn_ballot_w64(dmax2 < none2 * 0.999f) & cmask;
+        const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~allbodym;
+        const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < nw * 0.999f) & cmask & ~(allbodym | nonem);
         const uint64_t sureall = __builtin_amdgcn_ballot_w64(dmin2 > nw * 1.001f) & farm_all;
         // accepted by every body of the box: onto the far list while it has room
         const int rank = (int)mbcnt64(sureall);
@@ -273,7 +286,7 @@ __device__ __forceinline__ void build_group_lists(const typename Traversal<DIM>:
             snode[top + (int)mbcnt64(pushm)] = T::child(aux);
         top += (int)__popcll(pushm);
         // the rest: one seed entry per popped entry, holding those of its siblings that are left
-        const uint64_t restm = cmask & ~(openm | takem);
+        const uint64_t restm = cmask & ~(openm | takem | nonem);
         const uint32_t gm = (uint32_t)(restm >> (grp * GROUP)) & ((1u << GROUP) - 1u);
         const bool emit = sib == 0 && grp < npop && gm != 0u;
         const uint64_t emitm = __builtin_amdgcn_ballot_w64(emit);
@@ -351,7 +364,9 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
     // Bounding box of the wave's targets and their largest cell cutoff: a cell whose centre of
     // mass is farther from the box than that (with a margin far above float rounding) passes
     // the cutoff test for every lane and cannot be pruned.
-    float g0[DIM], g1[DIM], safe2 = thn2;
+    // The smallest cutoffs of the wave: a node closer than that to every point of the box lies
+    // inside every lane's cutoff distance.
+    float g0[DIM], g1[DIM], safe2 = thn2, in2 = thn2, ri_min = ri;
 #pragma unroll
     for (int d = 0; d < DIM; ++d)
         g0[d] = g1[d] = xi[d];
@@ -363,8 +378,11 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
             g1[d] = fmaxf(g1[d], __shfl_xor(g1[d], o));
         }
         safe2 = fmaxf(safe2, __shfl_xor(safe2, o));
+        in2 = fminf(in2, __shfl_xor(in2, o));
+        ri_min = fminf(ri_min, __shfl_xor(ri_min, o));
     }
     safe2 *= 1.001f;
+    in2 *= 0.999f;
 
     double sum[DIM];
 #pragma unroll
@@ -504,15 +522,34 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
                 dmax2 = __builtin_fmaf(f, f, dmax2);
             }
         }
-        const uint64_t bodym = __builtin_amdgcn_ballot_w64((int)wb < 0) & cmask;
-        const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~bodym;
-        const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < nw * 0.999f) & farm_all;
+        const uint64_t allbodym = __builtin_amdgcn_ballot_w64((int)wb < 0) & cmask;
+        // Nodes no lane gets anything from, and that no lane opens (barnesHut.cpp:59,75: contributions
+        // inside the cutoff distance are skipped): a body inside r_i + r_j + th of every lane; a cell
+        // without children inside 2 r_i + th of every lane (a lane that accepts it drops it, a lane
+        // that would open it finds nothing below); a cell that lies wholly inside th of every lane
+        // (its prune threshold: accepted it is dropped, and nothing below it can contribute).
+        // They are neither visited nor pushed.
+        float none2;
+        {
+            const float tb = ri_min - nw;  // a body: r_i + r_j + th for the lane with the smallest radius
+            const float inside = (T::child(aux) & 15u) != 0u ? __uint_as_float(T::prune(aux)) : in2;
+            none2 = (int)wb < 0 ? tb * tb : inside;
+        }
+        const uint64_t nonem = __builtin_amdgcn_ballot_w64(dmax2 < none2 * 0.999f) & cmask;
+        const uint64_t bodym = allbodym & ~nonem;
+        const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~allbodym;
+        // Cells every lane opens.  Near the cutoff a lane may see such a cell wholly inside its
+        // cutoff distance and not open it (the per-lane pruning); opened for that lane as well,
+        // everything below contributes nothing to it, which is the same result.
+        const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < nw * 0.999f) & cmask & ~(allbodym | nonem);
         const uint64_t sureall = __builtin_amdgcn_ballot_w64(dmin2 > nw * 1.001f) & farm_all;
         const uint64_t farcm = farm_all & ~(openm | sureall);
         // accepted by every lane AND visited for all of the wave's lanes: the plain force loop
         const uint64_t fullm = sureall & __builtin_amdgcn_ballot_w64(um == m0);
         const uint64_t surem = sureall & ~fullm;
-        const uint64_t nearm = cmask & ~(bodym | farm_all);
+        const uint64_t nearm = cmask & ~(allbodym | farm_all | openm | nonem);
+        if (STATS)
+            n_visit += (unsigned long long)__popcll(nonem);
         if (openm != 0ull) {
             // one entry per opened node that has children
             const uint64_t pushm = openm & __builtin_amdgcn_ballot_w64((T::child(aux) & 15u) != 0u);
@@ -542,7 +579,7 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
         slot_j = __builtin_amdgcn_inverse_ballot_w64(farcm) ? nsure + (int)mbcnt64(farcm) : slot_j;
         slot_j = __builtin_amdgcn_inverse_ballot_w64(nearm) ? nfar + (int)mbcnt64(nearm) : slot_j;
         slot_j = __builtin_amdgcn_inverse_ballot_w64(bodym) ? ncell + (int)mbcnt64(bodym) : slot_j;
-        const bool staged = __builtin_amdgcn_inverse_ballot_w64(cmask & ~openm);
+        const bool staged = __builtin_amdgcn_inverse_ballot_w64(cmask & ~(openm | nonem));
         if (staged) {
             batch[slot_j][0] = make_uint4(__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z),
                                           __float_as_uint(rec.w));
