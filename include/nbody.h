@@ -234,6 +234,12 @@ enum nb_debug_array {
                                [5] node visits summed over the 64-body groups, [6] node batches fetched,
                                [7] deepest traversal stack,
                                of the last Barnes-Hut step run with stage timing on */
+    NB_DBG_VISIT_KINDS = 11, /* 8 uint64: the node visits of NB_DBG_COUNTERS [5] by what the 64-body group made of the
+                               node before any lane looked at it: [0] opened by every lane (children pushed, no
+                               visit), [1] inside every lane's cutoff distance (dropped), [2] accepted by every
+                               lane, visited for all of them (force only), [3] the same under a lane mask,
+                               [4] per-lane opening test only (far from every cutoff), [5] all per-lane tests,
+                               [6] bodies, [7] per-lane cutoff test only (acceptance settled for the group) */
     NB_DBG_KEY_LEVELS = 10  /* 2 uint32: [0] the first tree level whose cells no body can open (wider cutoff
                                than opening distance; 32 = none), [1] the number of levels the keys hold:
                                bodies that share a cell of that level share a leaf */

@@ -630,6 +630,10 @@ int nb_debug_read(nb_sim *s, int which, void *out, size_t bytes, size_t *written
         src = s->bh.counters;
         need = sizeof(unsigned long long) * 8;
         break;
+    case NB_DBG_VISIT_KINDS:
+        src = s->bh.counters + 8;
+        need = sizeof(unsigned long long) * 8;
+        break;
     default:
         return fail(NB_ERR_ARG, "nb_debug_read: unknown array");
     }

@@ -320,6 +320,8 @@ int nb3_debug_read(nb_sim3 *s, int which, void *out, size_t bytes, size_t *writt
         return give(s->bh.cut, sizeof(uint32_t) * 2, true);
     case NB_DBG_COUNTERS:
         return give(s->bh.counters, sizeof(unsigned long long) * 8, true);
+    case NB_DBG_VISIT_KINDS:
+        return give(s->bh.counters + 8, sizeof(unsigned long long) * 8, true);
     default:
         return fail(NB_ERR_ARG, "nb3_debug_read: array not available in 3-D");
     }

@@ -51,7 +51,7 @@ struct BhBuffers {
     uint32_t *tlist = nullptr;    // sorted positions of this rank's targets (multi-GPU), else unused
     uint32_t *tcount = nullptr;   // 1 entry: number of targets in tlist
     uint32_t *tblock = nullptr;   // per-block target counts (scratch of the compaction)
-    unsigned long long *counters = nullptr;  // 8 statistics words
+    unsigned long long *counters = nullptr;  // 16 statistics words (NB_DBG_COUNTERS, NB_DBG_VISIT_KINDS)
     uint32_t *levels_host = nullptr;  // pinned host word: tree levels of the last finished step
     uint32_t *hint_host = nullptr;    // pinned host word: level of the leaves of the last finished step's tree
     double *hint_box = nullptr;       // pinned host: width and height of the last finished step's bounding box
@@ -62,9 +62,6 @@ struct BhBuffers {
     int launched = 0;                 // levels the per-level build kernels were launched for
     uint2 *pc_range = nullptr;        // dense pyramid: first and one-past-last sorted body of every cell of the
                                       // keys' last level (both zero: empty cell); null: no pyramid
-    uint2 *gl_hdr = nullptr;          // traversal: interaction lists per group of waves (nb_traverse.h GroupLists);
-    float4 *gl_far = nullptr;         //   null: none (buffers carved from a caller's arena), every wave starts
-    uint32_t *gl_seed = nullptr;      //   at the root
     double *agg = nullptr;            // cell exchange: one record per cell of the keys' last level (bh_cells_alloc)
     double *red4 = nullptr;           // cell exchange: {-min x, max x, -min y, max y} of the own bodies
     uint32_t *err = nullptr;          // (unused device word kept beside them)
@@ -116,7 +113,7 @@ int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], i
 // Level-by-level tree over sorted keys whose digits (bits = 2: quadtree, 3: octree) start at bit
 // 61.  node_meta: {first body, count, first child, child count | cell level << 8}; split:
 // (n + 256) * build_split_bytes(bits) bytes; level_start: BH_MAX_DEPTH + 2 words; bsum:
-// BH_SCAN_BLOCKS words; counters: 8 words, zeroed here.
+// BH_SCAN_BLOCKS words; counters: 16 words, zeroed here.
 size_t build_split_bytes(int bits);
 int level_blocks(int d, int bits, int nodes_per_block);  // grid of a per-level kernel (<= BH_SCAN_BLOCKS)
 int launched_levels(const uint32_t *levels_host);

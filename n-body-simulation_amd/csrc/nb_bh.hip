@@ -697,7 +697,7 @@ __device__ __forceinline__ void build_init(uint4 *node_meta, uint32_t *level_sta
         level_start[t] = t == 0 ? 0u : 1u;
     if (t == 0)
         node_meta[0] = make_uint4(0u, (uint32_t)n, 0u, 0u);
-    if (t < 8)
+    if (t < 16)
         counters[t] = 0ull;
 }
 
@@ -2005,7 +2005,7 @@ __global__ __launch_bounds__(256) void k_pyr_top(ComArgs a, uint4 *node_meta, ui
     // every slot of levels 0..L is a node slot; the levels of this tree are the cell levels
     if (threadIdx.x < BH_MAX_DEPTH + 2)
         level_start[threadIdx.x] = threadIdx.x == 0 ? 0u : (threadIdx.x == 1 ? 1u : pyr_offset(L + 1));
-    if (threadIdx.x < 8)
+    if (threadIdx.x < 16)
         counters[threadIdx.x] = threadIdx.x == 2 ? (unsigned long long)pyr_offset(L + 1)
                                                  : (threadIdx.x == 3 ? (unsigned long long)(L + 1) : 0ull);
 }
@@ -2110,7 +2110,6 @@ struct ForceArgs {
     IntegrateArgs ia;
     double theta;
     double collision_th;
-    GroupLists gl;           // interaction lists shared by the waves of a group (hdr null: none)
 };
 
 template <>
@@ -2119,9 +2118,6 @@ struct Traversal<2> {
     using Aux = uint2;
     static constexpr int GROUP = 4, ENTRIES = NB_TR_ENTRIES, HIGH = NB_TR_HIGH, DEPTH = 32, WPB = NB_TR_WPB;
     static constexpr bool EXTRA = false;      // the second staged word holds everything a visit needs
-    static constexpr bool LISTS = true;       // the waves of a group share interaction lists
-    // the stack entry that holds the siblings `mask` of the entry `entry`
-    static __device__ __forceinline__ uint32_t seed_entry(uint32_t entry, uint32_t mask) { return (entry & ~15u) | mask; }
     static constexpr int COM = 4, COM_W = 3;  // doubles per node_com record, index of the width
     // the target in the float coordinates of this step's records (ComArgs: relative to the middle
     // of the box); the traversal converts the FP64 position itself, no sorted record array exists
@@ -2183,12 +2179,6 @@ template <int MODE, bool STATS>
 __global__ __launch_bounds__(64 * TR_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bh_force(ForceArgs a)
 {
     traverse_and_integrate<2, MODE, STATS>(a);
-}
-
-template <bool STATS>
-__global__ __launch_bounds__(64) void k_bh_lists(ForceArgs a)
-{
-    build_group_lists<2, STATS>(a);
 }
 
 // ---- targets of this rank (multi-GPU): sorted positions k whose body lies in [t0, t1) ----
@@ -2286,19 +2276,6 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     dim3 grid((waves + TR_WPB - 1) / TR_WPB);
     if (ntarget <= 0)
         return NB_OK;
-#ifndef NB_TR_LISTS_OFF  // (tuning aid: every wave walks from the root)
-    if (b.gl_hdr) {
-        // the far tree is walked once per group of waves (nb_traverse.h)
-        f.gl.hdr = b.gl_hdr;
-        f.gl.far = b.gl_far;
-        f.gl.seed = b.gl_seed;
-        const dim3 lgrid((unsigned)list_groups(ntarget));
-        if (a.collect_stats)
-            hipLaunchKernelGGL(k_bh_lists<true>, lgrid, dim3(64), 0, s, f);
-        else
-            hipLaunchKernelGGL(k_bh_lists<false>, lgrid, dim3(64), 0, s, f);
-    }
-#endif
     const int mode = a.fc.exact_denom ? FM_EXACT : (a.fc.eps2_negligible ? FM_NOEPS : FM_EPS);
     if (a.collect_stats) {
         if (mode == FM_EXACT)
@@ -2456,15 +2433,10 @@ static int bh_layout(BhBuffers &b, int n, bool with_pyramid, Alloc &&alloc)
     NB_TRY(alloc(b.tlist, (size_t)n));
     NB_TRY(alloc(b.tcount, 4));
     NB_TRY(alloc(b.tblock, target_list_blocks(n)));
-    NB_TRY(alloc(b.counters, 8));
+    NB_TRY(alloc(b.counters, 16));
     if (with_pyramid) {
         // first / one-past-last sorted body of every cell of the deepest pyramid level
         NB_TRY(alloc(b.pc_range, (size_t)1 << (2 * b.pyr_max)));
-        // interaction lists of the traversal's groups of waves
-        const size_t groups = list_groups(n);
-        NB_TRY(alloc(b.gl_hdr, groups));
-        NB_TRY(alloc(b.gl_far, groups * LIST_FAR_CAP));
-        NB_TRY(alloc(b.gl_seed, groups * LIST_SEED_CAP));
     }
     return NB_OK;
 }
@@ -2541,9 +2513,6 @@ void bh_free(BhBuffers &b)
         (void)hipFree(b.tblock);
         (void)hipFree(b.counters);
         (void)hipFree(b.pc_range);
-        (void)hipFree(b.gl_hdr);
-        (void)hipFree(b.gl_far);
-        (void)hipFree(b.gl_seed);
         (void)hipFree(b.agg);
         (void)hipFree(b.red4);
         (void)hipFree(b.err);

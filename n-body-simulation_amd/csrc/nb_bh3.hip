@@ -493,7 +493,6 @@ struct Traversal<3> {
     using Aux = uint4;
     static constexpr int GROUP = 8, ENTRIES = NB_TR3_ENTRIES, HIGH = NB_TR3_HIGH, DEPTH = 21, WPB = NB_TR3_WPB;
     static constexpr bool EXTRA = true;       // the prune threshold is staged beside the two words
-    static constexpr bool LISTS = false;      // every wave walks from the root (packed children: a stack entry cannot hold a subset of siblings)
     static constexpr int COM = 6, COM_W = 4;  // doubles per node_com record, index of the width
     static __device__ __forceinline__ void load_target(const Args &a, int k, uint32_t, Pt<3> &x, float &ri)
     {
@@ -636,7 +635,7 @@ int bh3_alloc(Bh3Buffers &b, int n)
     NB_TRY(dev_alloc(b.tlist, (size_t)n));
     NB_TRY(dev_alloc(b.tcount, 4));
     NB_TRY(dev_alloc(b.tblock, target_list_blocks(n)));
-    NB_TRY(dev_alloc(b.counters, 8));
+    NB_TRY(dev_alloc(b.counters, 16));
     void *h = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
         return fail(NB_ERR_NOMEM, "hipHostMalloc failed");

@@ -24,9 +24,6 @@
 //                                float bits of the prune threshold (collision_th - cell diagonal)^2, or -1
 //   stage / staged accessors     what goes into the second staged word and how it is read back
 //   pos_ptr / load_acc / ...     FP64 state layout
-//   LISTS                        whether the waves of a group share interaction lists (GroupLists below);
-//                                then also seed_entry(entry, mask): the stack entry that holds the
-//                                siblings `mask` of a popped entry, and Args::gl
 #pragma once
 
 #include <type_traits>
@@ -118,206 +115,6 @@ struct TraversalSizes {
     static_assert(T::ENTRIES >= 1 && T::GROUP * T::ENTRIES <= 64, "one group of lanes per popped entry");
 };
 
-// ---- interaction lists shared by the waves of a group ----
-//
-// Neighbouring waves walk nearly the same far tree: the cells far away are accepted (or opened) by
-// every body of a whole neighbourhood alike.  A first kernel (build_group_lists), one wave per group
-// of LIST_WAVES consecutive traversal waves, walks the tree once for the bounding box of the
-// group's targets with the wave-level tests of the traversal itself and leaves per group
-//   far:   the records of the cells EVERY body in the box accepts (beyond every body's cutoff
-//          distance, with the traversal's margins): each wave of the group adds their forces in a
-//          loop that reads them through scalar loads -- no lane masks, no LDS;
-//   seed:  stack entries for everything else the walk met (cells some body of the box may open or
-//          judge differently, bodies): the waves start their own walks from these, not from the root.
-// Cells opened by every body of the box are descended by the list kernel and never seen by the
-// waves.  Every decision a lane makes for itself is unchanged: a cell is put on the far list only
-// when the wave-level test the traversal applies to the wave's own (smaller) box would accept it
-// for every lane too.  A group whose lists do not fit their rows falls back to the root as its
-// only seed.
-#ifndef NB_TR_LIST_WAVES
-#define NB_TR_LIST_WAVES 4
-#endif
-#ifndef NB_TR_LIST_FAR
-#define NB_TR_LIST_FAR 512
-#endif
-#ifndef NB_TR_LIST_SEED
-#define NB_TR_LIST_SEED 192
-#endif
-constexpr int LIST_WAVES = NB_TR_LIST_WAVES;    // traversal waves (of 64 targets) per group
-constexpr int LIST_FAR_CAP = NB_TR_LIST_FAR;    // far records per group (16 bytes each; rows start on 64-byte lines)
-constexpr int LIST_SEED_CAP = NB_TR_LIST_SEED;  // seed entries per group
-static_assert(LIST_FAR_CAP % 4 == 0 && LIST_SEED_CAP % 16 == 0, "rows of whole 64-byte lines");
-
-struct GroupLists {
-    uint2 *hdr = nullptr;      // per group: {far records, seed entries}; null: no lists, every wave starts at the root
-    float4 *far = nullptr;     // [group][LIST_FAR_CAP] node records
-    uint32_t *seed = nullptr;  // [group][LIST_SEED_CAP] stack entries
-};
-
-static inline size_t list_groups(int ntarget) { return ((size_t)ntarget + 64 * LIST_WAVES - 1) / (64 * LIST_WAVES); }
-
-// One wave per group of 64 LIST_WAVES consecutive targets (launch: list_groups(targets) blocks of 64).
-template <int DIM, bool STATS>
-__device__ __forceinline__ void build_group_lists(const typename Traversal<DIM>::Args &a)
-{
-    using T = Traversal<DIM>;
-    using Aux = typename T::Aux;
-    constexpr int GROUP = T::GROUP, ENTRIES = T::ENTRIES, HIGH = T::HIGH;
-    constexpr int STACK = TraversalSizes<DIM>::STACK;
-    __shared__ uint32_t snode[STACK];
-    const int lane = lane_id();
-    const int ntarget = a.tlist ? (int)*a.tcount : a.n;
-    // neighbouring groups walk mostly the same nodes: give them to one XCD's L2
-    const int group = (int)xcd_chunked_block(blockIdx.x, gridDim.x);
-    if ((size_t)group * (64 * LIST_WAVES) >= (size_t)ntarget)
-        return;
-    // bounding box of the group's targets, their largest cell cutoff, and whether any is dynamic
-    float g0[DIM], g1[DIM], safe2 = 0.f, in2 = __builtin_inff(), ri_min = __builtin_inff();
-    bool any_dynamic = false;
-#pragma unroll
-    for (int d = 0; d < DIM; ++d) {
-        g0[d] = __builtin_inff();
-        g1[d] = -__builtin_inff();
-    }
-#pragma unroll
-    for (int j = 0; j < LIST_WAVES; ++j) {
-        const int slot = (group * LIST_WAVES + j) * 64 + lane;
-        const bool valid = slot < ntarget;
-        const int last = valid ? slot : ntarget - 1;
-        const int k = a.tlist ? (int)a.tlist[last] : last;
-        const uint32_t body = a.idx[k];
-        Pt<DIM> xi;
-        float ri;
-        T::load_target(a, k, body, xi, ri);
-        const float thn = 2.f * ri + a.fc.cth;
-        safe2 = fmaxf(safe2, thn * thn);
-        in2 = fminf(in2, thn * thn);
-        ri_min = fminf(ri_min, ri);
-        any_dynamic = any_dynamic || (valid && a.dyn[body]);
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) {
-            g0[d] = fminf(g0[d], xi[d]);
-            g1[d] = fmaxf(g1[d], xi[d]);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) {
-            g0[d] = fminf(g0[d], __shfl_xor(g0[d], o));
-            g1[d] = fmaxf(g1[d], __shfl_xor(g1[d], o));
-        }
-        safe2 = fmaxf(safe2, __shfl_xor(safe2, o));
-        in2 = fminf(in2, __shfl_xor(in2, o));
-        ri_min = fminf(ri_min, __shfl_xor(ri_min, o));
-    }
-    safe2 *= 1.001f;
-    in2 *= 0.999f;
-    float4 *far = a.gl.far + (size_t)group * LIST_FAR_CAP;
-    uint32_t *seed = a.gl.seed + (size_t)group * LIST_SEED_CAP;
-    int nfar = 0, nseed = 0, top = 0;
-    bool overflow = false;
-    unsigned long long n_visit = 0, n_batch = 0;
-    if (__builtin_amdgcn_ballot_w64(any_dynamic) != 0ull) {
-        if (lane == 0)
-            snode[0] = 1u;  // the root as a group of one
-        top = 1;
-    }
-    while (top > 0) {
-        int npop = top < ENTRIES ? top : ENTRIES;
-        if (top > HIGH)
-            npop = 1;
-        const int grp = lane / GROUP, sib = lane % GROUP;
-        uint32_t ew = 0u, u = 0u;
-        bool have = false;
-        if (grp < npop) {
-            ew = snode[top - 1 - grp];
-            have = T::has(ew, sib);
-            u = (ew >> 4) + (uint32_t)sib;
-        }
-        const uint64_t cmask = __builtin_amdgcn_ballot_w64(have);
-        top -= npop;
-        __builtin_amdgcn_wave_barrier();
-        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-        Aux aux = T::no_aux();
-        if (have) {
-            rec = a.node_rec[u];
-            aux = a.node_aux[u];
-        }
-        // the wave-level tests of traverse_and_integrate, for the group's box
-        const uint32_t wb = T::wbits(rec, aux);
-        const float nw = __uint_as_float(wb);
-        float dmin2, dmax2;
-        {
-            const Pt<DIM> c = T::point(rec);
-            const float e0 = fmaxf(fmaxf(g0[0] - c[0], c[0] - g1[0]), 0.f);
-            const float f0 = fmaxf(c[0] - g0[0], g1[0] - c[0]);
-            dmin2 = e0 * e0;
-            dmax2 = f0 * f0;
-#pragma unroll
-            for (int d = 1; d < DIM; ++d) {
-                const float e = fmaxf(fmaxf(g0[d] - c[d], c[d] - g1[d]), 0.f);
-                const float f = fmaxf(c[d] - g0[d], g1[d] - c[d]);
-                dmin2 = __builtin_fmaf(e, e, dmin2);
-                dmax2 = __builtin_fmaf(f, f, dmax2);
-            }
-        }
-        const uint64_t allbodym = __builtin_amdgcn_ballot_w64((int)wb < 0) & cmask;
-        float none2;  // (see traverse_and_integrate: nodes no body of the box gets anything from)
-        {
-            const float tb = ri_min - nw;
-            const float inside = (T::child(aux) & 15u) != 0u ? __uint_as_float(T::prune(aux)) : in2;
-            none2 = (int)wb < 0 ? tb * tb : inside;
-        }
-        const uint64_t nonem = __builtin_amdgcn_ballot_w64(dmax2 < none2 * 0.999f) & cmask;
-        const uint64_t farm_all = __builtin_amdgcn_ballot_w64(dmin2 > safe2) & cmask & ~allbodym;
-        const uint64_t openm = __builtin_amdgcn_ballot_w64(dmax2 < nw * 0.999f) & cmask & ~(allbodym | nonem);
-        const uint64_t sureall = __builtin_amdgcn_ballot_w64(dmin2 > nw * 1.001f) & farm_all;
-        // accepted by every body of the box: onto the far list while it has room
-        const int rank = (int)mbcnt64(sureall);
-        const bool take = __builtin_amdgcn_inverse_ballot_w64(sureall) && nfar + rank < LIST_FAR_CAP;
-        const uint64_t takem = __builtin_amdgcn_ballot_w64(take);
-        if (take)
-            far[nfar + rank] = rec;
-        nfar += (int)__popcll(takem);
-        // opened by every body of the box: descend here
-        const uint64_t pushm = openm & __builtin_amdgcn_ballot_w64((T::child(aux) & 15u) != 0u);
-        if (__builtin_amdgcn_inverse_ballot_w64(pushm))
-            snode[top + (int)mbcnt64(pushm)] = T::child(aux);
-        top += (int)__popcll(pushm);
-        // the rest: one seed entry per popped entry, holding those of its siblings that are left
-        const uint64_t restm = cmask & ~(openm | takem | nonem);
-        const uint32_t gm = (uint32_t)(restm >> (grp * GROUP)) & ((1u << GROUP) - 1u);
-        const bool emit = sib == 0 && grp < npop && gm != 0u;
-        const uint64_t emitm = __builtin_amdgcn_ballot_w64(emit);
-        if (nseed + (int)__popcll(emitm) > LIST_SEED_CAP) {
-            overflow = true;
-            break;
-        }
-        if (emit)
-            seed[nseed + (int)mbcnt64(emitm)] = T::seed_entry(ew, gm);
-        nseed += (int)__popcll(emitm);
-        if (STATS) {
-            n_visit += (unsigned long long)__popcll(cmask);
-            n_batch += 1;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (overflow) {
-        // the rows are too short for this group: its waves walk from the root by themselves
-        nfar = 0;
-        nseed = 1;
-        if (lane == 0)
-            seed[0] = 1u;
-    }
-    if (lane == 0)
-        a.gl.hdr[group] = make_uint2((uint32_t)nfar, (uint32_t)nseed);
-    if (STATS && lane == 0) {
-        atomicAdd(&a.counters[5], n_visit);
-        atomicAdd(&a.counters[6], n_batch);
-    }
-}
-
 // One wave per 64 Morton-consecutive targets, eight waves per SIMD.
 template <int DIM, int MODE, bool STATS>
 __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<DIM>::Args &a)
@@ -389,65 +186,23 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
     for (int d = 0; d < DIM; ++d)
         sum[d] = 0.0;
     unsigned long long n_eval = 0, n_acc = 0, n_recheck = 0, n_visit = 0, n_batch = 0;
+    // visits by what the wave-level classification made of the node: opened by all, nothing for
+    // anybody, force only (all lanes / under a mask), per-lane opening test, full tests, bodies,
+    // per-lane cutoff test only
+    unsigned long long n_kind[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int max_top = 0;
 
     int top = 0;
     // every lane the wave computes a force for; a node visited for all of them needs no lane mask
     const uint64_t m0 = __builtin_amdgcn_ballot_w64(dynamic);
-    // the group's seed entries still to be walked: lane l holds entry win_base + l of them
-    int nseed = 0, seed_pos = 0, win_base = 0;
-    uint32_t win = 0u;
-    const uint32_t *seeds = nullptr;
     if (m0 != 0ull) {
-        bool from_root = true;
-        if constexpr (T::LISTS) {
-            if (a.gl.hdr) {
-                from_root = false;
-                const int group = __builtin_amdgcn_readfirstlane(wave / LIST_WAVES);
-                const uint2 h = a.gl.hdr[group];
-                const int nfar = __builtin_amdgcn_readfirstlane((int)h.x);
-                nseed = __builtin_amdgcn_readfirstlane((int)h.y);
-                seeds = a.gl.seed + (size_t)group * LIST_SEED_CAP;
-                win = lane < nseed ? seeds[lane] : 0u;
-                // Cells every body of the group accepts: only the force, records through scalar loads
-                // (written by an earlier kernel; the address is the same for all lanes).  FP32 sums
-                // go to the FP64 accumulators every 64 records, as after a batch of the walk.
-                typedef float f4 __attribute__((ext_vector_type(4)));
-                const __attribute__((address_space(4))) f4 *far =
-                    (const __attribute__((address_space(4))) f4 *)(a.gl.far + (size_t)group * LIST_FAR_CAP);
-                for (int j0 = 0; j0 < nfar; j0 += 64) {
-                    const int j1 = nfar < j0 + 64 ? nfar : j0 + 64;
-                    Pt<DIM> f;
-                    f.xy = (v2f)(0.f);
-                    f.z = 0.f;
-#pragma unroll 4
-                    for (int j = j0; j < j1; ++j) {
-                        const f4 r = far[j];
-                        const float4 rf = make_float4(r.x, r.y, r.z, r.w);
-                        const Pt<DIM> dv = pt_sub(T::point(rf), xi);
-                        const float d2 = pt_norm2(dv);
-                        pt_fma(f, dv, force_scale<MODE>(d2, T::mass(rf), eps2, eps3));
-                    }
-#pragma unroll
-                    for (int d = 0; d < DIM; ++d)
-                        sum[d] += (double)f[d];
-                }
-                if (STATS) {
-                    n_eval += (unsigned long long)nfar * __popcll(m0);
-                    n_acc += (unsigned long long)nfar * __popcll(m0);
-                    n_visit += (unsigned long long)nfar;
-                }
-            }
+        if (lane == 0) {
+            snode[0] = 1u;  // the root as a group of one
+            smask[0] = m0;
         }
-        if (from_root) {
-            if (lane == 0) {
-                snode[0] = 1u;  // the root as a group of one
-                smask[0] = m0;
-            }
-            top = 1;
-        }
+        top = 1;
     }
-    while (top > 0 || seed_pos < nseed) {
+    while (top > 0) {
         if (STATS) {
             n_batch += 1;
             max_top = top > max_top ? top : max_top;
@@ -465,27 +220,6 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
             have = T::has(ew, sib);
             u = (ew >> 4) + (uint32_t)sib;
             um = smask[top - 1 - grp];
-        }
-        if constexpr (T::LISTS) {
-            // Lane groups the stack leaves idle take the next seed entries (visited for every
-            // lane the wave computes a force for).  A round still holds at most ENTRIES entries,
-            // so the bound on the stack's growth stands.
-            if (seed_pos < nseed && top <= HIGH) {
-                int nfeed = ENTRIES - npop;
-                nfeed = nfeed < nseed - seed_pos ? nfeed : nseed - seed_pos;
-                nfeed = nfeed < win_base + 64 - seed_pos ? nfeed : win_base + 64 - seed_pos;
-                const uint32_t fed = (uint32_t)__shfl((int)win, seed_pos - win_base + grp - npop);
-                if (grp >= npop && grp < npop + nfeed) {
-                    have = T::has(fed, sib);
-                    u = (fed >> 4) + (uint32_t)sib;
-                    um = m0;
-                }
-                seed_pos += nfeed;
-                if (seed_pos == win_base + 64 && seed_pos < nseed) {
-                    win_base += 64;
-                    win = win_base + lane < nseed ? seeds[win_base + lane] : 0u;
-                }
-            }
         }
         const uint64_t cmask = __builtin_amdgcn_ballot_w64(have);  // lanes holding a node
         const int base = top - npop;
@@ -547,9 +281,25 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
         // accepted by every lane AND visited for all of the wave's lanes: the plain force loop
         const uint64_t fullm = sureall & __builtin_amdgcn_ballot_w64(um == m0);
         const uint64_t surem = sureall & ~fullm;
-        const uint64_t nearm = cmask & ~(allbodym | farm_all | openm | nonem);
-        if (STATS)
+        const uint64_t closem = cmask & ~(allbodym | farm_all | openm | nonem);  // cells near some lane's cutoff
+        // Of those, the cells whose acceptance is settled for the whole wave -- accepted by every
+        // lane, or without children: then width / theta < collision_th (the rule that closes the
+        // tree at such a level; a bucket leaf has width 0), so a lane outside 2 r_i + th of the
+        // centre of mass accepts the cell and a lane inside gets nothing either way -- need only
+        // the per-lane cutoff test (barnesHut.cpp:75).
+        const uint64_t dropm = closem & __builtin_amdgcn_ballot_w64((T::child(aux) & 15u) == 0u || dmin2 > nw * 1.001f);
+        const uint64_t nearm = closem & ~dropm;
+        if (STATS) {
             n_visit += (unsigned long long)__popcll(nonem);
+            n_kind[0] += (unsigned long long)__popcll(openm);
+            n_kind[1] += (unsigned long long)__popcll(nonem);
+            n_kind[2] += (unsigned long long)__popcll(fullm);
+            n_kind[3] += (unsigned long long)__popcll(surem);
+            n_kind[4] += (unsigned long long)__popcll(farcm);
+            n_kind[5] += (unsigned long long)__popcll(nearm);
+            n_kind[7] += (unsigned long long)__popcll(dropm);
+            n_kind[6] += (unsigned long long)__popcll(bodym);
+        }
         if (openm != 0ull) {
             // one entry per opened node that has children
             const uint64_t pushm = openm & __builtin_amdgcn_ballot_w64((T::child(aux) & 15u) != 0u);
@@ -572,12 +322,14 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
         // LDS broadcast), which keeps the per-node data off the vector ALU's lane-read path, and
         // each kind of node gets a loop without the other kinds' code.
         const int nfull = (int)__popcll(fullm), nsure = nfull + (int)__popcll(surem);
-        const int nfar = nsure + (int)__popcll(farcm), ncell = nfar + (int)__popcll(nearm);
+        const int nfar = nsure + (int)__popcll(farcm), ndrop = nfar + (int)__popcll(dropm);
+        const int ncell = ndrop + (int)__popcll(nearm);
         const int cstaged = ncell + (int)__popcll(bodym);
         int slot_j = (int)mbcnt64(fullm);
         slot_j = __builtin_amdgcn_inverse_ballot_w64(surem) ? nfull + (int)mbcnt64(surem) : slot_j;
         slot_j = __builtin_amdgcn_inverse_ballot_w64(farcm) ? nsure + (int)mbcnt64(farcm) : slot_j;
-        slot_j = __builtin_amdgcn_inverse_ballot_w64(nearm) ? nfar + (int)mbcnt64(nearm) : slot_j;
+        slot_j = __builtin_amdgcn_inverse_ballot_w64(dropm) ? nfar + (int)mbcnt64(dropm) : slot_j;
+        slot_j = __builtin_amdgcn_inverse_ballot_w64(nearm) ? ndrop + (int)mbcnt64(nearm) : slot_j;
         slot_j = __builtin_amdgcn_inverse_ballot_w64(bodym) ? ncell + (int)mbcnt64(bodym) : slot_j;
         const bool staged = __builtin_amdgcn_inverse_ballot_w64(cmask & ~(openm | nonem));
         if (staged) {
@@ -710,7 +462,35 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
         }
         for (int j = nsure; j < nfar; ++j)
             visit_cell(j, std::true_type{});
-        for (int j = nfar; j < ncell; ++j)
+        // ---- cells whose acceptance is settled: counted outside 2 r_i + th of the centre of mass ----
+        for (int j = nfar; j < ndrop; ++j) {
+            const uint4 r = batch[j][0];
+            const uint2 q2 = *(const uint2 *)&batch[j][1];
+            const float4 rf = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+            const uint64_t mj = lanes_of(make_uint4(q2.x, q2.y, 0u, 0u));
+            const Pt<DIM> dv = pt_sub(T::point(rf), xi);
+            const float d2 = pt_norm2(dv);
+            const float g2 = d2 - thn2;
+            uint64_t farm = __builtin_amdgcn_ballot_w64(g2 >= 0.f);
+            if ((__builtin_amdgcn_ballot_w64(__builtin_fabsf(g2) <= thn2_band) & mj) != 0ull) {
+                const double *nc = a.node_com + T::COM * (size_t)node_of(j);
+                farm = __builtin_amdgcn_ballot_w64(!(a.radius[body] * 2 + a.collision_th > dist64(nc)));
+                if (STATS)
+                    n_recheck += 1;
+            }
+            const uint64_t okm = mj & farm;
+            if (okm != 0ull) {
+                asm volatile("" ::: "memory");
+                const float sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? force_scale<MODE>(d2, T::mass(rf), eps2, eps3) : 0.f;
+                pt_fma(f, dv, sc);
+            }
+            if (STATS) {
+                n_eval += (unsigned long long)__popcll(mj);
+                n_acc += (unsigned long long)__popcll(okm);
+                n_visit += 1;
+            }
+        }
+        for (int j = ndrop; j < ncell; ++j)
             visit_cell(j, std::false_type{});
         // ---- bodies: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
         for (int j = ncell; j < cstaged; ++j) {
@@ -759,6 +539,8 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
         atomicAdd(&a.counters[5], n_visit);
         atomicAdd(&a.counters[6], n_batch);
         atomicMax(&a.counters[7], (unsigned long long)max_top);
+        for (int k = 0; k < 8; ++k)
+            atomicAdd(&a.counters[8 + k], n_kind[k]);
     }
     if (!valid)
         return;

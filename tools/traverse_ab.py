@@ -41,9 +41,11 @@ with nb.NBodySim(n, nb.BARNES_HUT) as sim:
         sim.update(1)
         sim.sync()
         c = sim.debug(nb.DBG_COUNTERS, np.uint64, 8)
+        kinds = sim.debug(nb.DBG_VISIT_KINDS, np.uint64, 8)
         sim.set_stage_timing(False, counters=False)
-        print("%-10s %-14s %.3f ms/step  %s | evals %.3g accepted %.3g visits %.3g batches %.3g stack %d" % (
-            tag, label, dt, " ".join("%s=%.3f" % kv for kv in st.items() if kv[1] > 0), c[0], c[1], c[5], c[6], c[7]), flush=True)
+        print("%-10s %-14s %.3f ms/step  %s | evals %.3g accepted %.3g visits %.3g batches %.3g stack %d | kinds(M) open %.2f none %.2f full %.2f sure %.2f farc %.2f near %.2f body %.2f drop %.2f" % (
+            tag, label, dt, " ".join("%s=%.3f" % kv for kv in st.items() if kv[1] > 0), c[0], c[1], c[5], c[6], c[7],
+            *(float(k) / 1e6 for k in kinds[:8])), flush=True)
 
     sim.update(3)
     timed("steps 3-13")
