@@ -210,6 +210,71 @@ def three_d_leg(nb, bh_n, direct_n, steps, warmup):
     return out
 
 
+XGMI_LINK_GBS = 153.0   # one xGMI link, one direction (MI355X: 7 links per GPU, one to each peer of an 8-GPU node)
+COLLECTIVE_LATENCY_MS = 0.03  # assumed fixed cost of one RCCL collective enqueued on a busy stream
+
+
+def per_rank_kernels(nb, alg, bodies, ranks, steps, warm):
+    """GPU time of ONE rank's kernels per step when the run is cut over `ranks` ranks, measured on this
+    GPU playing rank 0 (nb_set_partition(0, ranks); nb_step_local / nb_step_finish): its slice of the
+    targets against all sources, and for Barnes-Hut the whole tree (position exchange).  The other
+    ranks' bodies stand still here -- nobody advances them -- which leaves the work per step what it
+    is in a real run.  No collective runs: returns (ms per step summed over the stages, stage ms)."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    n = len(bodies)
+    with nb.NBodySim(n, alg) as sim:
+        sim.set_bodies(bodies)
+        sim.set_partition(0, ranks)
+
+        def step():
+            cur, chunk, rb = sim.exchange_buffer()
+            sim.step_local()
+            nxt = sim.exchange_buffer()[0]
+            if nxt != cur and n > chunk:
+                # direct sum: the new positions go to the other buffer; the slices of the other ranks
+                # (unchanged here) are what the all-gather would have delivered
+                sim.sync()
+                assert hip.hipMemcpy(nxt + chunk * rb, cur + chunk * rb, (n - chunk) * rb, 3) == 0
+            sim.step_finish()
+
+        for _ in range(warm):
+            step()
+        sim.set_stage_timing(True, counters=False)
+        for _ in range(steps):
+            step()
+        st = sim.stage_ms()
+    return sum(v for k, v in st.items() if k != "exchange"), {k: v for k, v in st.items() if v > 0 and k != "exchange"}
+
+
+def projected_scaling(nb, legs):
+    """What the first real multi-GPU run can be read against: per-rank kernel time MEASURED on this one
+    GPU (per_rank_kernels), the step's all-gather ESTIMATED from the link speed, and the speed-up over
+    the one-GPU step both give together.  legs: (name, alg, bodies, one-GPU ms/step, rank counts)."""
+    out = {"note": "kernel_ms: measured here, one rank's kernels of a run cut over that many ranks (this GPU as rank 0, "
+                   "position exchange: targets split, sources / tree replicated); allgather_ms: ESTIMATED, 16 B per body "
+                   "in place over xGMI -- 'direct' = every peer's slice over its own link at %.0f GB/s, 'ring' = ranks - 1 "
+                   "slices one after the other over one link -- plus %.2f ms per collective; no multi-GPU run stands "
+                   "behind these lines" % (XGMI_LINK_GBS, COLLECTIVE_LATENCY_MS)}
+    for name, alg, bodies, one_gpu_ms, rank_counts in legs:
+        n = len(bodies)
+        entry = {"n": n, "one_gpu_ms_per_step": one_gpu_ms, "ranks": {}}
+        for p in rank_counts:
+            steps, warm = (3, 1) if (alg == nb.DIRECT or n > 10000000) else (8, 3)
+            ms, st = per_rank_kernels(nb, alg, bodies, p, steps, warm)
+            slice_ms = 16.0 * n / p / (XGMI_LINK_GBS * 1e9) * 1e3
+            direct_ms = slice_ms + COLLECTIVE_LATENCY_MS
+            ring_ms = (p - 1) * slice_ms + COLLECTIVE_LATENCY_MS
+            entry["ranks"][str(p)] = {"kernel_ms": ms, "stage_ms": st,
+                                      "allgather_ms": {"direct": direct_ms, "ring": ring_ms},
+                                      "projected_speedup": {"direct": one_gpu_ms / (ms + direct_ms),
+                                                            "ring": one_gpu_ms / (ms + ring_ms)}}
+        out[name] = entry
+    return out
+
+
 def cpu_baseline(nb, bh_n):
     """The reference's own CPU Barnes-Hut (its classes, compiled unmodified into oracle/_ref; the
     plain-C port when that library is absent) timed on this host: ONE real step of the workload's
@@ -296,6 +361,8 @@ def main():
     ap.add_argument("--no-direct", action="store_true", help="skip the direct-sum half of the metric")
     ap.add_argument("--no-50m", action="store_true", help="skip the Barnes-Hut N = 50M leg (BASELINE.json configs[4])")
     ap.add_argument("--big-n", type=int, default=50000000)
+    ap.add_argument("--no-projection", action="store_true",
+                    help="one GPU: skip the per-rank kernel times of a run cut over 2/4/8 ranks (projected_scaling)")
     ap.add_argument("--position-exchange", action="store_true",
                     help="N > 1: all-gather the positions every step instead of the cell exchange")
     ap.add_argument("--late-step", type=int, default=300, help="also time the headline run from this step on (0: no)")
@@ -356,6 +423,11 @@ def main():
         gathered = {"ms_per_step": pdt * 1e3 / args.steps, "stage_ms": pstages,
                     "note": "the same workload with NB_EXCHANGE_POSITIONS: one all-gather of all positions per step, "
                             "sort + tree + centres of mass repeated on every GPU"}
+    projection_legs = []
+    project = world == 1 and not args.no_projection
+    if project:
+        projection_legs.append(("barnes_hut_n%d" % args.bh_n, nb.BARNES_HUT, bodies, ms_per_step, (2, 4, 8)))
+    proj = projected_scaling(nb, projection_legs) if project else None
     # the same workload on the tree of the reference's GPU program (depth-9 cap, leaves as point
     # masses): the configuration the published 1509 ms was measured with
     gdt, gstages, gcounters, _ = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device,
@@ -368,6 +440,10 @@ def main():
         bodies = nb.init_scenario(nb.SPIRAL, args.big_n, 12345)
         bdt, bstages, bcounters, _ = timed_run(nb, nb.BARNES_HUT, bodies, max(3, args.steps // 2), 2, rank, world, device,
                                                cells=cells)
+        if project:
+            proj.update({k: v for k, v in projected_scaling(
+                nb, [("barnes_hut_n%d" % args.big_n, nb.BARNES_HUT, bodies, bdt * 1e3 / max(3, args.steps // 2), (8,))]).items()
+                if k != "note"})
         del bodies
         big = {"n": args.big_n, "scenario": "spiral", "ms_per_step": bdt * 1e3 / max(3, args.steps // 2),
                "stage_ms": bstages, "tree": bcounters}
@@ -393,6 +469,9 @@ def main():
                                      "kernel_ms": kern_ms, "flop_per_interaction": FLOP_PER_INTERACTION,
                                      "traffic": None}
             direct["n%d" % n] = entry
+            if project and n == args.direct_n:
+                proj.update({k: v for k, v in projected_scaling(
+                    nb, [("direct_sum_n%d" % n, nb.DIRECT, b, ddt * 1e3 / steps, (2, 4, 8))]).items() if k != "note"})
 
     if rank != 0:
         if world > 1:
@@ -469,6 +548,7 @@ def main():
                                   "program, which itself is unpinned"},
         "roofline": roofline,
         "direct_sum": direct,
+        "projected_scaling": proj,
     }
     if world == 1 and not args.no_direct:
         out["three_d"] = three_d_leg(nb, args.bh_n, args.direct_n, args.steps, args.warmup)

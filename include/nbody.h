@@ -252,7 +252,8 @@ int nb_debug_read(nb_sim *sim, int which, void *out, size_t bytes, size_t *writt
  * collect the NB_DBG_COUNTERS statistics (slower traversal).
  * nb_stage_ms: mean milliseconds per stage over the steps (or nb_compute_accel calls) since the
  * previous nb_stage_ms call or since timing was switched on:
- * [0] bbox [1] keys [2] sort [3] build [4] com [5] force+integrate [6] exchange: the collectives of
+ * [0] bbox [1] keys [2] sort [3] build (direct sum with a partition: re-packing the float records of the
+ * bodies other ranks advanced) [4] com [5] force+integrate [6] exchange: the collectives of
  * nb_step_distributed, or with nb_step_cells whatever the stream did between the parts of a step
  * (0 otherwise). */
 int nb_set_stage_timing(nb_sim *sim, int on);

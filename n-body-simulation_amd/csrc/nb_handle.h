@@ -250,8 +250,11 @@ int step_finish(S *s)
     s->stepped = true;
     s->count_step();
     if (s->alg == NB_ALG_DIRECT) {
-        if (s->world > 1)  // records of the bodies other ranks advanced come from the gathered positions
+        if (s->world > 1) {  // records of the bodies other ranks advanced come from the gathered positions
+            s->timer.mark(s->stream, 3);  // (timed as the direct sum's "build" stage)
             NB_TRY(s->direct_pack_others());
+            s->timer.mark(s->stream, StageTimer::STAGE_END);
+        }
         s->direct_flip();
         std::swap(s->pos, s->pos2);
     }

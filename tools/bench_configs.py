@@ -65,7 +65,7 @@ def run3(alg, scenario, n, steps, thickness, warm=2):
     print("%-22s N=%-9d thick %.0e %9.3f ms/step  %s" % (name, n, thickness, dt * 1e3, extra), flush=True)
 
 
-def ranks(world, n, steps, cells, scenario=2):
+def ranks(world, n, steps, cells, scenario=2, alg=None):
     """Per-rank GPU time of a run cut over `world` ranks, measured with `world` handles on this one
     GPU (the collectives are done through the host between the parts of a step and are not timed):
     what each rank's kernels cost, stage by stage, rank 0 and the slowest rank."""
@@ -73,7 +73,8 @@ def ranks(world, n, steps, cells, scenario=2):
 
     hip = pe._hip()
     b = nb.init_scenario(scenario, n, 12345)
-    sims = [nb.NBodySim(n, nb.BARNES_HUT) for _ in range(world)]
+    alg = nb.BARNES_HUT if alg is None else alg
+    sims = [nb.NBodySim(n, alg) for _ in range(world)]
     try:
         for r, s in enumerate(sims):
             s.set_bodies(b)
@@ -138,7 +139,7 @@ def ranks(world, n, steps, cells, scenario=2):
     tot = [sum(v for k, v in st.items() if k != "exchange") for st in per]
     worst = int(np.argmax(tot))
     fmt = lambda st: " ".join("%s=%.3f" % kv for kv in st.items() if kv[1] > 0)  # noqa: E731
-    print("BH %s N=%d world=%d %s: rank 0 %.3f ms [%s]; slowest rank %d %.3f ms [%s]" % (
+    print(("BH" if alg == nb.BARNES_HUT else "direct sum") + " %s N=%d world=%d %s: rank 0 %.3f ms [%s]; slowest rank %d %.3f ms [%s]" % (
         {0: "spiral", 2: "collision"}[scenario], n, world,
         {0: "position exchange", 1: "cell exchange", 2: "cell exchange (auto)"}[int(cells)],
         tot[0], fmt(per[0]), worst, tot[worst], fmt(per[worst])), flush=True)
@@ -157,6 +158,11 @@ if "ranks" in which:
     for world in (2, 4, 8):
         ranks(world, 5000000, 5, nb.EXCHANGE_CELLS)
         ranks(world, 5000000, 5, nb.EXCHANGE_POSITIONS)
+if "ranks_direct" in which:
+    # per-rank kernels of the direct sum cut over 2, 4, 8 ranks: force = k_sub_meta + k_direct + k_direct_finish
+    # (the source split is what direct_set_split chooses for the slice), build = re-packing the other ranks' records
+    for world in (2, 4, 8):
+        ranks(world, 1000000, 3, 0, scenario=0, alg=nb.DIRECT)
 if "d3" in which:
     run3(nb.DIRECT, nb.SPIRAL, 65536, 20, 5.0e10)
     run3(nb.BARNES_HUT, nb.SPIRAL, 1000000, 10, 5.0e10)
