@@ -77,7 +77,7 @@ int nb_sim::alloc_pipelines()
         jsplit = direct_choose_jsplit(n, n);
         part_cap = (size_t)jsplit * n;
         NB_TRY(dev_alloc(part, part_cap));
-        NB_TRY(dev_alloc(ds_meta, direct_meta_bytes(n)));
+        NB_TRY(dev_alloc(ds_meta, 2 * direct_meta_bytes(n)));  // one set of boxes per record buffer
     } else {
         NB_TRY(dev_alloc(mass_radius, cap));
         NB_TRY(bh_alloc(bh, n));
@@ -100,7 +100,8 @@ int nb_sim::direct_step(int do_integrate)
 {
     timer.mark(stream, 5);
     NB_TRY(nb::direct_step(stream, posm[cur], posm[cur ^ 1], rad_s, n, t0, t1 - t0, fc, make_integrate_args(this, do_integrate),
-                           dyn, pos2d(), pos2d_next(), radius, p.collision_th, vel2d(), acc2d(), part, jsplit, ds_meta));
+                           dyn, pos2d(), pos2d_next(), radius, p.collision_th, vel2d(), acc2d(), part, jsplit,
+                           ds_meta + cur * direct_meta_bytes(n), ds_meta + (cur ^ 1) * direct_meta_bytes(n), &ds_meta_valid));
     timer.mark(stream, 6);
     return NB_OK;
 }
@@ -128,6 +129,7 @@ int nb_sim::bh_step(int do_integrate)
 int nb_sim::direct_pack_all()
 {
     cur = 0;
+    ds_meta_valid = false;
     NB_TRY(pack_posm(stream, pos2d(), mass, radius, n, 0, n, units, p.collision_th, posm[0], rad_s));
     NB_TRY(pad_posm(stream, posm[0], n));
     // mass and cutoff radius never change: give the second buffer the same records
@@ -137,6 +139,7 @@ int nb_sim::direct_pack_all()
 
 int nb_sim::direct_pack_others()
 {
+    ds_meta_valid = false;
     NB_TRY(pack_posm(stream, pos2d_next(), mass, radius, n, 0, t0, units, p.collision_th, posm[cur ^ 1], rad_s));
     return pack_posm(stream, pos2d_next(), mass, radius, n, t1, n, units, p.collision_th, posm[cur ^ 1], rad_s);
 }

@@ -82,10 +82,14 @@ struct IntegrateArgs {
 // posm: {x, y, m, radius + collision_th} per body in internal units (float4), n records.
 // Integrates targets [t0, t0+nt): reads posm_cur and pos_cur, writes vel/acc and the targets'
 // entries of pos_next and posm_next (nothing the step reads is written by it).  part: scratch of jsplit*nt double2 when jsplit > 1.
+// meta / meta_next: direct_meta_bytes(n) each, the bounding boxes of the source runs of posm_cur /
+// posm_next; *meta_valid: on entry whether meta holds the boxes of posm_cur (computed first
+// otherwise), on return whether the step left in meta_next the boxes of posm_next (a step that
+// advances all bodies does) or, for a force evaluation, whether meta still holds those of posm_cur.
 int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const float *rad, int n, int t0, int nt,
                 const ForceConsts &fc, const IntegrateArgs &ia, const uint8_t *dyn, const double2 *pos_cur,
                 double2 *pos_next, const double *radius, double collision_th, double2 *vel, double2 *acc,
-                double2 *part, int jsplit, void *meta);
+                double2 *part, int jsplit, void *meta, void *meta_next, bool *meta_valid);
 int direct_choose_jsplit(int n, int nt);
 // Record arrays handed to direct_step hold direct_record_capacity(n) float4, the ones past n
 // written by pad_posm (the kernel stages whole tiles).

@@ -47,8 +47,11 @@ constexpr int DS_BLOCK = 256;
 #define NB_DS_TILE 512
 #endif
 constexpr int DS_TILE = NB_DS_TILE;  // records per LDS tile (8 KiB), two buffers
+// (256 -> 128: the boxes are tighter and fewer pairs of a wave and a run count as near, 4.71 -> 4.84
+// T interactions/s at N = 65 536, 5.62 -> 5.74 at 262 144, 5.89 -> 5.95 at 1 M; 64: 4.87 / 5.64 /
+// 5.82, the per-run scalar work begins to show; 32: 4.64 / 4.98 / 4.98)
 #ifndef NB_DS_SUB
-#define NB_DS_SUB 256
+#define NB_DS_SUB 128
 #endif
 constexpr int DS_SUB = NB_DS_SUB;  // records per run with its own bounding box
 #ifndef NB_DS_FLUSH
@@ -85,6 +88,7 @@ struct DirectLaunch {
     double2 *pos_next;       // FP64 positions after the step
     const double *radius;
     const SubMeta *meta;
+    SubMeta *meta_out;       // where the step leaves the boxes of the records it writes (null: nowhere)
     double collision_th;
     double2 *vel;
     double2 *acc;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void k_sub_meta(const float4 *posm, int n, Sub
 }
 
 // v += a dt; x += v dt for one body, and its refreshed float record.
-__device__ __forceinline__ void integrate_one(const DirectLaunch &a, int i, double sx, double sy, float4 rec)
+__device__ __forceinline__ float4 integrate_one(const DirectLaunch &a, int i, double sx, double sy, float4 rec)
 {
     double ax = 0.0, ay = 0.0;
     if (a.dyn[i]) {
@@ -168,6 +172,63 @@ __device__ __forceinline__ void integrate_one(const DirectLaunch &a, int i, doub
         rec.y = (float)qy;
         a.posm_next[i] = rec;
         a.posl_next[i] = make_float2((float)(qx - (double)rec.x), (float)(qy - (double)rec.y));
+    }
+    return rec;
+}
+
+// The boxes of the runs whose new records a 256-thread block has just written, one record per thread
+// (thread t: body first + t, the block's first body a multiple of DS_SUB): what k_sub_meta would
+// compute from those records at the start of the next step.  All threads of the block call.
+__device__ __forceinline__ void block_meta_store(SubMeta *meta_out, int first, float4 rec, bool valid)
+{
+    static_assert(DS_SUB % 64 == 0 && 256 % DS_SUB == 0, "whole waves per run, whole runs per block");
+    constexpr int WPR = DS_SUB / 64;  // waves per run
+    __shared__ float part[4][7];
+    float v[7] = {__builtin_inff(), -__builtin_inff(), __builtin_inff(), -__builtin_inff(), 0.f, __builtin_inff(), -__builtin_inff()};
+    if (valid) {
+        v[0] = v[1] = rec.x;
+        v[2] = v[3] = rec.y;
+        v[4] = rec.w;
+        v[5] = v[6] = rec.z;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v[0] = fminf(v[0], __shfl_xor(v[0], o));
+        v[1] = fmaxf(v[1], __shfl_xor(v[1], o));
+        v[2] = fminf(v[2], __shfl_xor(v[2], o));
+        v[3] = fmaxf(v[3], __shfl_xor(v[3], o));
+        v[4] = fmaxf(v[4], __shfl_xor(v[4], o));
+        v[5] = fminf(v[5], __shfl_xor(v[5], o));
+        v[6] = fmaxf(v[6], __shfl_xor(v[6], o));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+            part[w][q] = v[q];
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && w % WPR == 0) {
+#pragma unroll
+        for (int k = 1; k < WPR; ++k) {
+            v[0] = fminf(v[0], part[w + k][0]);
+            v[1] = fmaxf(v[1], part[w + k][1]);
+            v[2] = fminf(v[2], part[w + k][2]);
+            v[3] = fmaxf(v[3], part[w + k][3]);
+            v[4] = fmaxf(v[4], part[w + k][4]);
+            v[5] = fminf(v[5], part[w + k][5]);
+            v[6] = fmaxf(v[6], part[w + k][6]);
+        }
+        if (v[0] <= v[1]) {  // the run holds a body
+            SubMeta m;
+            m.x0 = v[0];
+            m.x1 = v[1];
+            m.y0 = v[2];
+            m.y1 = v[3];
+            m.wmax = v[4];
+            m.mu = (v[5] == v[6]) ? v[5] : __builtin_nanf("");
+            m.pad0 = m.pad1 = 0.f;
+            meta_out[(first + 64 * w) / DS_SUB] = m;
+        }
     }
 }
 
@@ -510,16 +571,21 @@ __global__ __launch_bounds__(DS_BLOCK) NB_DS_OCC void k_direct(DirectLaunch a)
 // Sums the jsplit partial accelerations of each target in split order, then integrates.
 __global__ __launch_bounds__(256) void k_direct_finish(DirectLaunch a)
 {
-    const int i = a.t0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.t0 + a.nt)
-        return;
-    double sx = 0.0, sy = 0.0;
-    for (int s = 0; s < a.jsplit; ++s) {
-        const double2 p = a.part[(size_t)s * a.nt + (i - a.t0)];
-        sx += p.x;
-        sy += p.y;
+    const int first = a.t0 + blockIdx.x * 256;
+    const int i = first + (int)threadIdx.x;
+    const bool valid = i < a.t0 + a.nt;
+    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+        double sx = 0.0, sy = 0.0;
+        for (int s = 0; s < a.jsplit; ++s) {
+            const double2 p = a.part[(size_t)s * a.nt + (i - a.t0)];
+            sx += p.x;
+            sy += p.y;
+        }
+        rec = integrate_one(a, i, sx, sy, a.posm_cur[i]);
     }
-    integrate_one(a, i, sx, sy, a.posm_cur[i]);
+    if (a.meta_out)  // (uniform: every thread of the block gets there)
+        block_meta_store(a.meta_out, first, rec, valid);
 }
 
 __global__ __launch_bounds__(256) void k_pack_posm(const double2 *pos, const double *mass, const double *radius, int i0,
@@ -605,7 +671,7 @@ int direct_choose_jsplit(int n, int nt)
 int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const float *rad, int n, int t0, int nt,
                 const ForceConsts &fc, const IntegrateArgs &ia, const uint8_t *dyn, const double2 *pos_cur,
                 double2 *pos_next, const double *radius, double collision_th, double2 *vel, double2 *acc,
-                double2 *part, int jsplit, void *meta)
+                double2 *part, int jsplit, void *meta, void *meta_next, bool *meta_valid)
 {
     if (nt <= 0)
         return NB_OK;
@@ -636,8 +702,22 @@ int direct_step(hipStream_t s, const float4 *posm_cur, float4 *posm_next, const 
     a.ia = ia;
     if (a.jsplit > 1 && !part)
         return fail(NB_ERR_ARG, "direct_step: split sources need a partial buffer");
+    // The boxes of the source runs: computed here unless the step before left them (a step that
+    // advances every body writes, with the new records, the boxes they will have as sources).
     const int nsub = (n + DS_SUB - 1) / DS_SUB;
-    hipLaunchKernelGGL(k_sub_meta, dim3((nsub + 3) / 4), dim3(256), 0, s, posm_cur, n, (SubMeta *)meta);
+    if (!*meta_valid)
+        hipLaunchKernelGGL(k_sub_meta, dim3((nsub + 3) / 4), dim3(256), 0, s, posm_cur, n, (SubMeta *)meta);
+    // (the finishing kernel does that; a step without one -- a few hundred bodies -- computes them as before)
+#ifdef NB_DS_NO_FUSED_META  // (tuning aid: the boxes always come from k_sub_meta)
+    const bool all_advance = false;
+#else
+    const bool all_advance = ia.do_integrate && t0 == 0 && nt == n && a.jsplit > 1;
+#endif
+    // (into the other buffer: blocks of this launch still read the present boxes)
+    a.meta_out = all_advance ? (SubMeta *)meta_next : nullptr;
+    // records unchanged (a force evaluation): the boxes stay; only some records rewritten here (a
+    // partitioned run: the rest arrives from other ranks): computed again next time
+    *meta_valid = all_advance || !ia.do_integrate;
     dim3 grid((nt + DS_BLOCK * DS_TPT - 1) / (DS_BLOCK * DS_TPT), a.jsplit);
     if (fc.exact_denom && fc.precise_near)
         hipLaunchKernelGGL((k_direct<DS_TPT, true, true>), grid, dim3(DS_BLOCK), 0, s, a);

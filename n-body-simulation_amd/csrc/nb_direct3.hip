@@ -23,7 +23,10 @@ namespace nb {
 constexpr int DS3_BLOCK = 256;
 constexpr int DS3_TPT = 2;
 constexpr int DS3_TILE = 1024;
-constexpr int DS3_SUB = 256;
+#ifndef NB_DS3_SUB
+#define NB_DS3_SUB 256
+#endif
+constexpr int DS3_SUB = NB_DS3_SUB;
 constexpr int DS3_FLUSH = 32;
 constexpr float DS3_BAND = 4.0e-5f;      // see DS_BAND in nb_direct.hip
 constexpr float DS3_GAP_SLACK = 1.0005f;  // relative margin on the box gap of a far run ...

@@ -34,7 +34,8 @@ struct nb_sim : nb::SimCore<2> {
     int cur = 0;
     double2 *part = nullptr;  // part_cap records
     int jsplit = 1;
-    uint8_t *ds_meta = nullptr;  // per-run bounding boxes (direct_meta_bytes)
+    uint8_t *ds_meta = nullptr;  // per-run bounding boxes (2 x direct_meta_bytes: one set per record buffer)
+    bool ds_meta_valid = false;  // the set of the current record buffer is up to date
 
     // Barnes-Hut
     nb::BhBuffers bh;

@@ -21,7 +21,10 @@ with nb.NBodySim3(n, nb.BARNES_HUT) as sim:
     sim.set_stage_timing(False, counters=True)
     sim.update(1)
     c = sim.debug(nb.DBG_COUNTERS, np.uint64, 8)
+    kinds = sim.debug(nb.DBG_VISIT_KINDS, np.uint64, 8)
 print(os.path.basename(os.environ.get("NBODY_HIP_LIB", "default")), "N=%d" % n,
       " ".join("%s %.3f" % kv for kv in st.items()), "total %.3f" % sum(st.values()),
       "| evals %.3g acc %.3g nodes %d redo %d visits %.3g batches %.3g (%.1f/batch) stack %d"
-      % (c[0], c[1], c[2], c[4], c[5], c[6], c[5] / max(1, c[6]), c[7]), flush=True)
+      % (c[0], c[1], c[2], c[4], c[5], c[6], c[5] / max(1, c[6]), c[7]),
+      "| kinds(M) open %.1f none %.1f full %.1f sure %.1f farc %.1f near %.1f body %.1f drop %.1f" % tuple(float(k) / 1e6 for k in kinds),
+      flush=True)
