@@ -361,6 +361,9 @@ def main():
     ap.add_argument("--no-direct", action="store_true", help="skip the direct-sum half of the metric")
     ap.add_argument("--no-50m", action="store_true", help="skip the Barnes-Hut N = 50M leg (BASELINE.json configs[4])")
     ap.add_argument("--big-n", type=int, default=50000000)
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline run (and its late states): no GPU-tree mode, N = 50M, direct sum, 3-D, CPU or "
+                         "projection legs -- what the counter passes of profiles/collect.sh run")
     ap.add_argument("--no-projection", action="store_true",
                     help="one GPU: skip the per-rank kernel times of a run cut over 2/4/8 ranks (projected_scaling)")
     ap.add_argument("--position-exchange", action="store_true",
@@ -370,6 +373,8 @@ def main():
                     help="and once more from this step on (ejected bodies have stretched the box: the tree closes at level 11); "
                          "0 or --late-step 0: no")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu = args.no_direct = args.no_50m = args.no_projection = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Started without a launcher: start one rank per GPU ourselves.  Nothing in this process
@@ -430,8 +435,10 @@ def main():
     proj = projected_scaling(nb, projection_legs) if project else None
     # the same workload on the tree of the reference's GPU program (depth-9 cap, leaves as point
     # masses): the configuration the published 1509 ms was measured with
-    gdt, gstages, gcounters, _ = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device,
-                                           params=nb.default_params(bucket_depth=9))
+    gdt, gstages, gcounters = 0.0, {}, None
+    if not args.headline_only:
+        gdt, gstages, gcounters, _ = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device,
+                                               params=nb.default_params(bucket_depth=9))
     del bodies
 
     # ---- BASELINE.json configs[4]: Barnes-Hut, spiral galaxy N = 50M (on 1..8 GPUs) ----
@@ -485,20 +492,55 @@ def main():
     achieved = alg_bytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else 0.0
     traffic = None
     l2_hit = None
+    profiled = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1:
         try:
-            measured = json.load(open(tpath)).get("k_bh_force", {})
+            profiled = json.load(open(tpath))
+            measured = profiled.get("k_bh_force", {})
             traffic = measured.get("hbm_bytes_per_launch")
             l2_hit = measured.get("l2_hit_rate")
         except Exception:
             traffic = None
+
+    def issue_roofline(counters_of, kernel_ms):
+        """The kernel against the rate at which a SIMD issues instructions: the vector and LDS instructions
+        the counter passes recorded per launch (profiles/traffic.json), priced in issue slots by the
+        static mix of the kernel's hot loop (profiles/issue_census.py), over this run's kernel time."""
+        census = profiled.get("issue_census") or {}
+        got = profiled.get(counters_of) or {}
+        if "slots_per_vector_instruction" not in census or "valu_wave_insts" not in got or not kernel_ms:
+            return None
+        slots = (got["valu_wave_insts"] * census["slots_per_vector_instruction"]
+                 + got.get("lds_wave_insts", 0.0) * census["slots_per_lds_instruction"])
+        rate = slots / (kernel_ms * 1e-3)
+        return {"bound": "vector issue", "unit": "wave-instruction slots/s", "achieved": rate,
+                "peak": census["issue_rate_wave_slots_per_s"], "frac": rate / census["issue_rate_wave_slots_per_s"],
+                "slots_per_launch": slots, "valu_wave_insts": got["valu_wave_insts"],
+                "salu_wave_insts": got.get("salu_wave_insts"), "lds_wave_insts": got.get("lds_wave_insts"),
+                "slots_per_vector_instruction": census["slots_per_vector_instruction"],
+                "slots_per_lds_instruction": census["slots_per_lds_instruction"],
+                "source": "SQ_INSTS_VALU / SQ_INSTS_LDS per launch from the rocprofv3 --pmc pass recorded in profiles/traffic.json "
+                          "(%s); slot weights and the issue rate (v_fma_f32: 58 T lane-ops/s) measured by bin/microbench; "
+                          "not counters of this run" % got.get("workload", "")}
     roofline = {"bound": "hbm", "kernel": "k_bh_force", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "l2_hit_rate": l2_hit, "kernel_ms": force_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "traffic_source": "profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE (and TCC hits / (hits + misses)) of this kernel from separate "
-                                  "rocprofv3 --pmc passes over `bench.py --steps 2 --warmup 1` (steps 2-3 of this "
-                                  "workload), not measured in this run"}
+                                  "rocprofv3 --pmc passes over `bench.py --steps 2 --warmup 1 --headline-only` (steps 2-3 of "
+                                  "this workload), not measured in this run"}
+    roofline["issue"] = issue_roofline("k_bh_force", force_ms)
+    if late and world == 1:
+        # the late state has its own counters (steps 300-301 of the same workload)
+        lforce = (late.get("stage_ms") or {}).get("force", 0.0)
+        lt = profiled.get("k_bh_force_late") or {}
+        if lforce > 0:
+            late["roofline"] = {"bound": "hbm", "kernel": "k_bh_force", "kernel_ms": lforce,
+                                "achieved": alg_bytes / (lforce * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": alg_bytes / (lforce * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "traffic": lt.get("hbm_bytes_per_launch"), "l2_hit_rate": lt.get("l2_hit_rate"),
+                                "traffic_source": "profiles/traffic.json k_bh_force_late (%s)" % lt.get("workload", "not collected"),
+                                "issue": issue_roofline("k_bh_force_late", lforce)}
     if counters and force_ms > 0:
         roofline["body_node_interactions_per_s"] = counters["accepted_interactions"] / (force_ms * 1e-3)
         roofline["node_evaluations_per_s"] = counters["node_evaluations"] / (force_ms * 1e-3)
@@ -541,11 +583,12 @@ def main():
         "late_state": late,
         "position_exchange": gathered,
         "barnes_hut_50m": big,
-        "gpu_tree_mode": {"ms_per_step": gdt * 1e3 / args.steps, "bucket_depth": 9, "stage_ms": gstages, "tree": gcounters,
-                          "speedup_vs_published": PUBLISHED_MS / (gdt * 1e3 / args.steps),
-                          "note": "nb_params.bucket_depth = 9: the reference GPU program's tree (cells not split below "
-                                  "level 9, leaves as point masses); checked against the oracle's restatement of that "
-                                  "program, which itself is unpinned"},
+        "gpu_tree_mode": None if args.headline_only else {
+            "ms_per_step": gdt * 1e3 / args.steps, "bucket_depth": 9, "stage_ms": gstages, "tree": gcounters,
+            "speedup_vs_published": PUBLISHED_MS / (gdt * 1e3 / args.steps),
+            "note": "nb_params.bucket_depth = 9: the reference GPU program's tree (cells not split below "
+                    "level 9, leaves as point masses); checked against the oracle's restatement of that "
+                    "program, which itself is unpinned"},
         "roofline": roofline,
         "direct_sum": direct,
         "projected_scaling": proj,

@@ -39,8 +39,17 @@ def main():
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(out, rnd + "_bench.json"))
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
+        for r in rows:
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # The counter passes run the headline workload alone: its first three steps, then on to step 300
+    # and two more.  The launches of the traversal kernel are taken apart accordingly (in dispatch
+    # order): "@early" = the first three, "@late" = the last two.
+    for k in [k for k in pmc if k.startswith("k_bh_force<") and "false" in k]:
+        for c, v in list(pmc[k].items()):
+            if len(v) >= 8:
+                pmc[k + "@early"][c] = v[:3]
+                pmc[k + "@late"][c] = v[-2:]
     summary = {}
     for k, cs in sorted(pmc.items()):
         summary[k] = {c: {"launches": len(v), "mean": sum(v) / len(v), "max": max(v)} for c, v in sorted(cs.items())}
@@ -57,23 +66,29 @@ def main():
         return {c.replace("SQ_INSTS_", "").lower(): counters[c]["mean"] / visits
                 for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in counters} | {"wave_node_visits": visits}
 
-    plain = [k for k in summary if k.startswith("k_bh_force<") and "false" in k]
+    plain = [k for k in summary if k.startswith("k_bh_force<") and "false" in k and k.endswith("@early")]
     if plain:
         line = json.loads(open(os.path.join(src, "bench.json")).read().strip().split("\n")[-1])
         summary["k_bh_force_per_visit"] = {rnd: per_visit(summary[plain[0]], line)}
+        accepted = (line.get("tree") or {}).get("accepted_interactions")
+        if accepted:
+            summary["k_bh_force_per_accepted_interaction"] = {
+                c.replace("SQ_INSTS_", "").lower() + "_lane_slots": summary[plain[0]][c]["mean"] * 64 / accepted
+                for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in summary[plain[0]]}
         prev = "r%02d" % (int(rnd[1:]) - 1)
         try:
             old = json.load(open(os.path.join(out, prev + "_pmc.json")))
             old_line = json.loads(open(os.path.join(out, prev + "_bench.json")).read().strip().split("\n")[-1])
-            old_plain = [k for k in old if k.startswith("k_bh_force<") and "false" in k]
+            old_plain = [k for k in old if k.startswith("k_bh_force<") and "false" in k and "@" not in k]
             summary["k_bh_force_per_visit"][prev] = per_visit(old[old_plain[0]], old_line)
         except (OSError, ValueError, IndexError, KeyError):
             pass
     json.dump(summary, open(os.path.join(out, rnd + "_pmc.json"), "w"), indent=1, sort_keys=True)
     traffic = {}
-    # the traversal instantiation the bench ran most often (the other is its statistics variant)
-    runs = [(v.get("FETCH_SIZE", {}).get("launches", 0), k) for k, v in summary.items() if k.startswith("k_bh_force<")]
-    for k, tag in ((max(runs)[1] if runs else "", "k_bh_force"),):
+    # the plain traversal instantiation (the other is its statistics variant), early and late
+    base = [k[: -len("@early")] for k in summary if k.startswith("k_bh_force<") and "false" in k and k.endswith("@early")]
+    for k, tag, what in ((base[0] + "@early" if base else "", "k_bh_force", "steps 2-3 after the bodies are set"),
+                         (base[0] + "@late" if base else "", "k_bh_force_late", "steps 300-301")):
         if k in summary and "FETCH_SIZE" in summary[k] and "WRITE_SIZE" in summary[k]:
             fetch = summary[k]["FETCH_SIZE"]["mean"] * 1024
             write = summary[k]["WRITE_SIZE"]["mean"] * 1024
@@ -83,9 +98,21 @@ def main():
                 "fetch_bytes_doubled": 2 * fetch,
                 "write_bytes": write,
                 "l2_hit_rate": summary[k].get("l2_hit_rate"),
-                "workload": "galaxy collision N=5,000,000, steps 2-3 after the bodies are set (bench.py --steps 2 --warmup 1)",
+                "workload": "galaxy collision N=5,000,000, %s (bench.py --steps 2 --warmup 1 --headline-only "
+                            "--late-step 300 --later-step 0)" % what,
                 "round": rnd,
             }
+            for c, name in (("SQ_INSTS_VALU", "valu_wave_insts"), ("SQ_INSTS_SALU", "salu_wave_insts"),
+                            ("SQ_INSTS_LDS", "lds_wave_insts")):
+                if c in summary[k]:
+                    traffic[tag][name] = summary[k][c]["mean"]
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from issue_census import census
+
+        traffic["issue_census"] = census()
+    except Exception as e:  # no hipcc here: the counters stand without the weights
+        traffic["issue_census"] = {"error": str(e)}
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(traffic, indent=1))
 
