@@ -115,3 +115,25 @@ def test_coincident_bodies_are_reported(oracle):
     b["pos"][3] = b["pos"][7]
     with pytest.raises(ValueError):
         oracle.bh_accel(b)
+
+
+def test_config0_through_the_reference_cpu_classes(oracle):
+    """BASELINE.json configs[0] -- random-body init, N = 4096, direct sum, 100 steps on the reference's
+    CPU path, headless -- run through the reference's own classes (NBody(n, 0, 1): DirectSum,
+    initRandomBodies; compiled unmodified into oracle/_ref by oracle/Makefile) where that library
+    was built, and against the fixture it left (tests/golden/random_n4096.npz) everywhere: the run
+    reproduces the fixture to the last bit, and the plain-C restatement follows it to 1e-12.  (The
+    product has no CPU path: its run of the same configuration is
+    test_gpu_direct.py::test_random_scenario_trajectory[random_n4096].)"""
+    from oracle_lib import Reference
+
+    g = golden("random_n4096")
+    if Reference.available():
+        ref = Reference()
+        b0 = ref.scenario(1, 4096, 12345)
+        assert np.array_equal(b0["pos"], g["pos0"]) and np.array_equal(b0["mass"], g["mass"])
+        end = ref.step(0, b0, 100)
+        assert np.array_equal(end["pos"], g["pos_direct_100"])
+        assert np.array_equal(end["vel"], g["vel_direct_100"])
+    port = oracle.direct_step(bodies_from_golden(g), 100)
+    assert close(port["pos"], g["pos_direct_100"]) and close(port["vel"], g["vel_direct_100"])
