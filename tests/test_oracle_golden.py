@@ -121,8 +121,8 @@ def test_config0_through_the_reference_cpu_classes(oracle):
     """BASELINE.json configs[0] -- random-body init, N = 4096, direct sum, 100 steps on the reference's
     CPU path, headless -- run through the reference's own classes (NBody(n, 0, 1): DirectSum,
     initRandomBodies; compiled unmodified into oracle/_ref by oracle/Makefile) where that library
-    was built, and against the fixture it left (tests/golden/random_n4096.npz) everywhere: the run
-    reproduces the fixture to the last bit, and the plain-C restatement follows it to 1e-12.  (The
+    was built: the run reproduces the fixture it left (tests/golden/random_n4096.npz) to the last bit
+    (test_scenarios_and_steps_golden pins the plain-C restatement to the same fixture at 1e-12).  (The
     product has no CPU path: its run of the same configuration is
     test_gpu_direct.py::test_random_scenario_trajectory[random_n4096].)"""
     from oracle_lib import Reference
@@ -135,5 +135,5 @@ def test_config0_through_the_reference_cpu_classes(oracle):
         end = ref.step(0, b0, 100)
         assert np.array_equal(end["pos"], g["pos_direct_100"])
         assert np.array_equal(end["vel"], g["vel_direct_100"])
-    port = oracle.direct_step(bodies_from_golden(g), 100)
-    assert close(port["pos"], g["pos_direct_100"]) and close(port["vel"], g["vel_direct_100"])
+    else:  # (test_scenarios_and_steps_golden[4096-1-random] steps the restatement through the same 100 steps)
+        pytest.skip("oracle/_ref/libnbody_ref.so was not built here")
