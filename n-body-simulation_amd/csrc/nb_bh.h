@@ -33,7 +33,7 @@ struct BhBuffers {
                                   // [3] 1: this step builds the dense pyramid, 0: the level-by-level tree,
                                   // [4] the level of the tree's leaves (= [1] except in a cell-exchange step)
     uint32_t *hist = nullptr;     // 256 x sort blocks
-    uint32_t *hist_totals = nullptr;  // 256: keys per digit of the current pass
+    uint32_t *hist_totals = nullptr;  // sort_totals_words(): keys per digit and row segment of the current pass
     int sort_blocks = 0;
     double *leaf_sum = nullptr;   // 4 doubles per sorted body: sums over the run of equal keys starting there
     uint32_t *chunk_info = nullptr;  // per 64 sorted bodies: first lane that starts a run (64: none) |
@@ -102,12 +102,13 @@ struct BhStepArgs {
 // Pieces the 3-D pipeline (nb_bh3.hip) shares.
 // Stable LSD radix sort of (key, index) pairs by key << 2, ping-pong between the two buffers;
 // the result is in buffer 0.  cut[2] = first pass with work (sort_first_pass in nb_dev.h); the
-// unsorted pairs must be in buffer cut[2] & 1.  hist: sort_hist_words(n) words, totals: 256.
+// unsorted pairs must be in buffer cut[2] & 1.  hist: sort_hist_words(n) words, totals: sort_totals_words().
 // first_launch: passes below it are not even launched -- only for a caller that chose the key width
 // itself and so knows that cut[2] >= first_launch, or that makes the device keep cut[2] at or above
 // it (bh_sort); 0 launches all eight (the device decides).
 int sort_blocks(int n);
 size_t sort_hist_words(int n);
+size_t sort_totals_words();
 int sort_pairs(hipStream_t s, uint64_t *const keys[2], uint32_t *const idx[2], int n, const uint32_t *cut, uint32_t *hist,
                uint32_t *totals, int first_launch = 0);
 // Level-by-level tree over sorted keys whose digits (bits = 2: quadtree, 3: octree) start at bit

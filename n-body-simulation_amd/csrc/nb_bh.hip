@@ -521,7 +521,7 @@ static int bh_layout(BhBuffers &b, int n, bool with_pyramid, Alloc &&alloc)
         NB_TRY(alloc(b.idx[k], (size_t)n));
     }
     NB_TRY(alloc(b.hist, (size_t)SORT_BINS * b.sort_blocks));
-    NB_TRY(alloc(b.hist_totals, SORT_BINS));
+    NB_TRY(alloc(b.hist_totals, sort_totals_words()));
     NB_TRY(alloc(b.node_meta, b.node_cap));
     NB_TRY(alloc(b.split, (size_t)n + 256));  // one Split<2> (16 bytes) per frontier slot
     NB_TRY(alloc(b.level_start, BH_MAX_DEPTH + 2));

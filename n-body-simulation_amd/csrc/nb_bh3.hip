@@ -616,7 +616,7 @@ int bh3_alloc(Bh3Buffers &b, int n)
         NB_TRY(dev_alloc(b.idx[k], (size_t)n));
     }
     NB_TRY(dev_alloc(b.hist, sort_hist_words(n)));
-    NB_TRY(dev_alloc(b.hist_totals, 256));
+    NB_TRY(dev_alloc(b.hist_totals, sort_totals_words()));
     NB_TRY(dev_alloc(b.leaf_sum, 6 * (size_t)n));
     NB_TRY(dev_alloc(b.chunk_info, (size_t)n / 64 + 2));
     NB_TRY(dev_alloc(b.posm_s, (size_t)n));

@@ -31,6 +31,10 @@ constexpr int SORT_PACK_LEVELS = 15;        // key digits that leave bits 31..0 
 constexpr int SORT_PACK_MAX_N = 1 << 30;    // the index stays below bit 30, the lowest bit a sort pass with work reads
 constexpr uint32_t SORT_PACK_MASK = (1u << 30) - 1u;
 constexpr int SORT_BINS = 256;  // 8-bit digits
+#ifndef NB_SORT_SEGS
+#define NB_SORT_SEGS 16
+#endif
+constexpr int SORT_SEGS = NB_SORT_SEGS;  // segments a digit's row of per-block counts is scanned in
 
 constexpr int BBOX_BLOCKS = 1024;
 

@@ -161,7 +161,7 @@ int refresh_alloc(RefreshBuffers &r, int n)
         NB_TRY(dev_alloc(r.idx[k], (size_t)n));
     }
     NB_TRY(dev_alloc(r.hist, sort_hist_words(n)));
-    NB_TRY(dev_alloc(r.totals, 256));
+    NB_TRY(dev_alloc(r.totals, sort_totals_words()));
     NB_TRY(dev_alloc(r.cut, 8));
     NB_TRY(dev_alloc(r.part, (size_t)RF_BLOCKS * 6));
     NB_TRY(dev_alloc(r.box, 6));
