@@ -4,8 +4,8 @@
 Compiles n-body-simulation_amd/csrc/nb_bh.hip to gfx950 assembly (hipcc cross-compiles without a
 GPU), takes the plain instantiation of k_bh_force (no statistics, no softening) and counts, over the
 blocks of its main loop that hold no FP64 arithmetic (the FP64 re-decisions are cold), the vector
-instructions by what they cost to issue on an MI355X SIMD, as bin/microbench measured it
-(DESIGN.md section 4): a plain FP32 / integer vector op 1 slot, a packed FP32 op (v_pk_*) 2, v_rsq /
+instructions by what they cost to issue on an MI355X SIMD, as bin/microbench
+(n-body-simulation_amd/csrc/microbench.hip) measured it: a plain FP32 / integer vector op 1 slot, a packed FP32 op (v_pk_*) 2, v_rsq /
 v_rcp / v_sqrt 2, an op that writes a lane mask or moves a lane to a scalar register (v_cmp*,
 v_readfirstlane, v_readlane) 1.6.  The mean of those weights is what one counted vector
 instruction (SQ_INSTS_VALU) is priced at; an LDS instruction is priced at 3.3 plain ops (a
