@@ -53,7 +53,7 @@ struct nb_sim3 : SimCore<3> {
             part_cap = 3 * (size_t)ds.jsplit * n;
             NB_TRY(dev_alloc(ds.part, part_cap));
             uint8_t *meta = nullptr;
-            NB_TRY(dev_alloc(meta, direct3_meta_bytes(n)));
+            NB_TRY(dev_alloc(meta, 2 * direct3_meta_bytes(n)));  // one set of boxes per record buffer
             ds.meta = meta;
             return NB_OK;
         }
@@ -123,6 +123,7 @@ struct nb_sim3 : SimCore<3> {
     int direct_pack_all()
     {
         ds.cur = 0;
+        ds.meta_valid = false;
         NB_TRY(pack_posm3(stream, pos, mass, radius, n, units, p.collision_th, ds.posm[0], ds.wcut, ds.rad));
         // masses and padding never change: the other buffer starts as a copy
         NB_HIP(hipMemcpyAsync(ds.posm[1], ds.posm[0], sizeof(float4) * 2 * direct3_record_capacity(n), hipMemcpyDeviceToDevice,
@@ -132,6 +133,7 @@ struct nb_sim3 : SimCore<3> {
 
     int direct_pack_others()
     {
+        ds.meta_valid = false;
         NB_TRY(pack_posm3_range(stream, pos2, mass, n, 0, t0, units, ds.posm[ds.cur ^ 1]));
         return pack_posm3_range(stream, pos2, mass, n, t1, n, units, ds.posm[ds.cur ^ 1]);
     }

@@ -78,7 +78,7 @@ struct IntegrateArgs {
     int static_fixed;  // 1: bodies that are not dynamic keep their position and velocity
 };
 
-// ---- direct sum (nb_direct.hip) ----
+// ---- direct sum (nb_direct.hip; kernels in nb_direct_impl.h) ----
 // posm: {x, y, m, radius + collision_th} per body in internal units (float4), n records.
 // Integrates targets [t0, t0+nt): reads posm_cur and pos_cur, writes vel/acc and the targets'
 // entries of pos_next and posm_next (nothing the step reads is written by it).  part: scratch of jsplit*nt double2 when jsplit > 1.
@@ -99,7 +99,7 @@ int pad_posm(hipStream_t s, float4 *posm, int n);
 size_t direct_meta_bytes(int n);
 
 // pos/mass/radius (double) -> posm records + scaled radius, bodies [i0, i1)
-// n: bodies in all (the low parts of the coordinates live behind the records, see direct_lo).
+// n: bodies in all (the low parts of the coordinates live behind the records: DirectTraits<2>::lo_of).
 int pack_posm(hipStream_t s, const double2 *pos, const double *mass, const double *radius, int n, int i0, int i1,
               const Units &units, double collision_th, float4 *posm, float *rad);
 // A record array holds direct_record_floats4(n) float4: direct_record_capacity(n) records and,

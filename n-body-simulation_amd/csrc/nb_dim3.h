@@ -15,7 +15,7 @@
 
 namespace nb {
 
-// ---- direct sum (nb_direct3.hip) ----
+// ---- direct sum (nb_direct3.hip; kernels in nb_direct_impl.h) ----
 struct Direct3State {
     float4 *posm[2] = {nullptr, nullptr};  // {x, y, z, m} per body, internal units; [cur] is current; each holds
                                            // 2 * direct3_record_capacity(n) float4: behind the records, the
@@ -31,7 +31,8 @@ struct Direct3State {
     double *vel = nullptr, *acc = nullptr;
     double *part = nullptr;  // jsplit x targets x 3 partial sums
     int jsplit = 1;
-    void *meta = nullptr;  // direct3_meta_bytes(n)
+    void *meta = nullptr;     // 2 x direct3_meta_bytes(n): the boxes of the source runs, one set per record buffer
+    bool meta_valid = false;  // the set of posm[cur] is up to date (direct3_step keeps this; cleared when records are packed)
 };
 
 size_t direct3_record_capacity(int n);
@@ -45,7 +46,7 @@ int pack_posm3_range(hipStream_t s, const double *pos, const double *mass, int n
                      float4 *posm);
 // One step for targets [t0, t0 + nt): reads posm[cur] and pos_cur, writes the targets' vel, acc,
 // pos_next and posm[cur ^ 1].
-int direct3_step(hipStream_t s, const Direct3State &st, int n, int t0, int nt, const ForceConsts &fc, const IntegrateArgs &ia,
+int direct3_step(hipStream_t s, Direct3State &st, int n, int t0, int nt, const ForceConsts &fc, const IntegrateArgs &ia,
                  double collision_th);
 
 // ---- Barnes-Hut (nb_bh3.hip) ----

@@ -159,7 +159,7 @@ if "ranks" in which:
         ranks(world, 5000000, 5, nb.EXCHANGE_CELLS)
         ranks(world, 5000000, 5, nb.EXCHANGE_POSITIONS)
 if "ranks_direct" in which:
-    # per-rank kernels of the direct sum cut over 2, 4, 8 ranks: force = k_sub_meta + k_direct + k_direct_finish
+    # per-rank kernels of the direct sum cut over 2, 4, 8 ranks: force = k_run_boxes + k_direct + k_direct_finish
     # (the source split is what direct_set_split chooses for the slice), build = re-packing the other ranks' records
     for world in (2, 4, 8):
         ranks(world, 1000000, 3, 0, scenario=0, alg=nb.DIRECT)
