@@ -29,9 +29,10 @@
 // Per interaction, far run: DIM sub, DIM fma, 1 rsq, 2-3 mul, DIM fma; near run: + add, fma, cmp,
 // select and the tie test.  Bound: FP32 vector ALU (no MFMA: no dense contraction here).
 //
-// DirectTraits<DIM> gives: TPT, TILE, SUB, FLUSH, NEAR_UNROLL, SPLIT (sources per unit a slice of
-// the source range is counted in), W_IN_RECORD, the type Lo of a record's low parts, and the
-// accessors coords / mass / cutoff / with_coords / make_lo / pad_record / make_record.
+// DirectTraits<DIM> gives: TPT (targets per thread, even), TILE, SUB, FLUSH, NEAR_UNROLL, SPLIT
+// (sources per unit a slice of the source range is counted in), W_IN_RECORD (the record carries the
+// cutoff radius), the type Lo of a record's low parts, and the accessors coords / mass / cutoff /
+// lo_parts / with_coords / make_record / make_lo / pad_record / lo_of.
 #pragma once
 
 #include "nb_common.h"
