@@ -10,6 +10,7 @@
 // nb_direct.hip and nb_bh.hip, the cell exchange between GPUs, diagnostics and introspection.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -50,6 +51,9 @@ BhStepArgs bh_args(nb_sim *s, int do_integrate)
     a.collision_th = s->p.collision_th;
     a.bucket_depth = s->p.bucket_depth;
     a.collect_stats = s->collect_stats;
+    a.from = s->body_arrays(false);
+    if (do_integrate && s->keeps_order_fresh())
+        a.to = s->body_arrays(true);
     return a;
 }
 
@@ -81,6 +85,18 @@ int nb_sim::alloc_pipelines()
     } else {
         NB_TRY(dev_alloc(mass_radius, cap));
         NB_TRY(bh_alloc(bh, n));
+        // the second set of per-body arrays (85 bytes per body); NB_KEEP_SLOTS in the environment: none,
+        // every body keeps its slot and the order is renewed every so many steps (tuning aid)
+        if (std::getenv("NB_KEEP_SLOTS"))
+            return static_scratch_init(device);
+        NB_TRY(dev_alloc(pos2, 2 * cap));
+        NB_TRY(dev_alloc(vel_b, 2 * cap));
+        NB_TRY(dev_alloc(acc_b, 2 * cap));
+        NB_TRY(dev_alloc(mass_b, cap));
+        NB_TRY(dev_alloc(radius_b, cap));
+        NB_TRY(dev_alloc(mass_radius_b, cap));
+        NB_TRY(dev_alloc(dyn_b, cap));
+        NB_TRY(dev_alloc(order_b, cap));
     }
     return static_scratch_init(device);
 }
@@ -88,6 +104,13 @@ int nb_sim::alloc_pipelines()
 void nb_sim::free_pipelines()
 {
     (void)hipFree(mass_radius);
+    (void)hipFree(vel_b);
+    (void)hipFree(acc_b);
+    (void)hipFree(mass_b);
+    (void)hipFree(radius_b);
+    (void)hipFree(mass_radius_b);
+    (void)hipFree(dyn_b);
+    (void)hipFree(order_b);
     (void)hipFree(posm[0]);
     (void)hipFree(posm[1]);
     (void)hipFree(rad_s);
@@ -123,7 +146,33 @@ int nb_sim::bh_step(int do_integrate)
     timer.mark(stream, 5);
     NB_TRY(bh_force(stream, bh, a));
     timer.mark(stream, 6);
+    if (a.to.pos) {
+        // the step left the bodies in the other set of arrays, in the order of its tree
+        std::swap(pos, pos2);
+        std::swap(vel, vel_b);
+        std::swap(acc, acc_b);
+        std::swap(mass, mass_b);
+        std::swap(radius, radius_b);
+        std::swap(mass_radius, mass_radius_b);
+        std::swap(dyn, dyn_b);
+        std::swap(order_d, order_b);
+        order_stale = true;
+    }
     return NB_OK;
+}
+
+BodyArrays2 nb_sim::body_arrays(bool other) const
+{
+    BodyArrays2 r;
+    r.pos = (double2 *)(other ? pos2 : pos);
+    r.vel = (double2 *)(other ? vel_b : vel);
+    r.acc = (double2 *)(other ? acc_b : acc);
+    r.mass = other ? mass_b : mass;
+    r.radius = other ? radius_b : radius;
+    r.mass_radius = other ? mass_radius_b : mass_radius;
+    r.dyn = other ? dyn_b : dyn;
+    r.order = other ? order_b : order_d;
+    return r;
 }
 
 int nb_sim::direct_pack_all()
@@ -255,6 +304,7 @@ static BhStepArgs cells_args(nb_sim *s, int do_integrate)
     a.n = s->t1 - s->t0;
     a.t0 = 0;
     a.t1 = a.n;
+    a.to = BodyArrays2();  // (world > 1 here: every body keeps its slot)
     return a;
 }
 

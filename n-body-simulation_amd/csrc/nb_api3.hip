@@ -41,6 +41,7 @@ struct nb_sim3 : SimCore<3> {
     Bh3Buffers bh;
 
     bool static_fixed() const { return false; }
+    bool keeps_order_fresh() const { return false; }
 
     int alloc_pipelines()
     {

@@ -78,6 +78,15 @@ void bh_free(BhBuffers &b);
 // with base == nullptr only *used (bytes needed for n bodies) is computed.
 int bh_carve(BhBuffers &b, int n, void *base, size_t bytes, size_t *used);
 
+// The per-body arrays of a 2-D simulation (one of its two sets).
+struct BodyArrays2 {
+    double2 *pos = nullptr, *vel = nullptr, *acc = nullptr;
+    double *mass = nullptr, *radius = nullptr;
+    double2 *mass_radius = nullptr;
+    uint8_t *dyn = nullptr;
+    uint32_t *order = nullptr;  // caller index of the body in each slot
+};
+
 struct BhStepArgs {
     const double2 *pos;
     const double *mass;
@@ -97,6 +106,13 @@ struct BhStepArgs {
     double collision_th;
     int bucket_depth;  // 0: one body per leaf; k: leaves are the cells of level k (point masses)
     int collect_stats;
+    // to.pos != null: the step leaves the bodies in ITS sorted order in the arrays of `to` (the body at
+    // sorted position k in slot k: pos, vel, acc as the step computes them, everything else copied from
+    // `from`), and the arrays it read keep the old state.  Only for a step of all n bodies (t0 = 0,
+    // t1 = n, ia.do_integrate).  The sort's permutation then stays close to the identity, and the leaf
+    // pass's and the traversal's gathers through it close to coalesced: a run that keeps its slots loses
+    // that within a handful of steps as the bodies mix.
+    BodyArrays2 from, to;
 };
 
 // Pieces the 3-D pipeline (nb_bh3.hip) shares.

@@ -367,6 +367,10 @@ struct ForceArgs {
     double2 *pos;
     double2 *vel;
     double2 *acc;
+    // where the step writes: the same arrays, or (to.pos != null) slot k of the arrays in `to` for the
+    // body at sorted position k, every other per-body array carried along
+    double2 *pos_w, *vel_w, *acc_w;
+    BodyArrays2 from, to;
     unsigned long long *counters;
     int n;
     ForceConsts fc;
@@ -414,9 +418,10 @@ struct Traversal<2> {
     static __device__ __forceinline__ float staged_prune(const uint4 &q, const float *, int) { return __uint_as_float(q.w); }
     static __device__ __forceinline__ uint32_t staged_child(const uint4 &q) { return q.z; }
     static __device__ __forceinline__ const double *pos_ptr(const Args &a, uint32_t body) { return (const double *)(a.pos + body); }
-    static __device__ __forceinline__ void store_acc(const Args &a, uint32_t body, const double (&acc)[2])
+    static __device__ __forceinline__ uint32_t dest(const Args &a, uint32_t body, uint32_t k) { return a.to.pos ? k : body; }
+    static __device__ __forceinline__ void store_acc(const Args &a, uint32_t dst, const double (&acc)[2])
     {
-        a.acc[body] = make_double2(acc[0], acc[1]);
+        a.acc_w[dst] = make_double2(acc[0], acc[1]);
     }
     static __device__ __forceinline__ void load_acc(const Args &a, uint32_t body, double (&acc)[2])
     {
@@ -424,7 +429,7 @@ struct Traversal<2> {
         acc[0] = t.x;
         acc[1] = t.y;
     }
-    static __device__ __forceinline__ void integrate(const Args &a, uint32_t body, const double (&acc)[2])
+    static __device__ __forceinline__ void integrate(const Args &a, uint32_t body, uint32_t dst, const double (&acc)[2])
     {
         double2 v = a.vel[body];
         double2 p = a.pos[body];
@@ -432,8 +437,25 @@ struct Traversal<2> {
         v.y += acc[1] * a.ia.dt_kick;
         p.x += v.x * a.ia.dt;
         p.y += v.y * a.ia.dt;
-        a.vel[body] = v;
-        a.pos[body] = p;
+        a.vel_w[dst] = v;
+        a.pos_w[dst] = p;
+    }
+    // A step that re-orders the bodies: what it did not write itself goes to the new slot too.
+    static __device__ __forceinline__ void carry(const Args &a, uint32_t body, uint32_t dst, bool dynamic, bool advanced)
+    {
+        if (!a.to.pos)
+            return;  // uniform
+        if (!dynamic)
+            a.to.acc[dst] = a.acc[body];
+        if (!advanced) {
+            a.to.pos[dst] = a.pos[body];
+            a.to.vel[dst] = a.vel[body];
+        }
+        a.to.mass_radius[dst] = a.from.mass_radius[body];
+        a.to.mass[dst] = a.from.mass[body];
+        a.to.radius[dst] = a.from.radius[body];
+        a.to.dyn[dst] = a.from.dyn[body];
+        a.to.order[dst] = a.from.order[body];
     }
 };
 constexpr int TR_WPB = Traversal<2>::WPB;
@@ -470,6 +492,13 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     f.pos = a.pos_out;
     f.vel = a.vel;
     f.acc = a.acc;
+    f.from = a.from;
+    f.to = a.to;
+    if (f.to.pos && (f.tlist || !a.ia.do_integrate))
+        return fail(NB_ERR_ARG, "bh_force: only a step of all the bodies can re-order them");
+    f.pos_w = f.to.pos ? f.to.pos : f.pos;
+    f.vel_w = f.to.pos ? f.to.vel : f.vel;
+    f.acc_w = f.to.pos ? f.to.acc : f.acc;
     f.counters = b.counters;
     f.n = a.n;
     f.fc = a.fc;

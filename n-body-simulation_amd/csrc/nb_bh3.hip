@@ -531,7 +531,10 @@ struct Traversal<3> {
         for (int d = 0; d < 3; ++d)
             acc[d] = a.acc[3 * (size_t)body + d];
     }
-    static __device__ __forceinline__ void integrate(const Args &a, uint32_t body, const double (&acc)[3])
+    // (the octree step leaves every body in its slot)
+    static __device__ __forceinline__ uint32_t dest(const Args &, uint32_t body, uint32_t) { return body; }
+    static __device__ __forceinline__ void carry(const Args &, uint32_t, uint32_t, bool, bool) {}
+    static __device__ __forceinline__ void integrate(const Args &a, uint32_t body, uint32_t, const double (&acc)[3])
     {
         for (int d = 0; d < 3; ++d) {
             const double v = a.vel[3 * (size_t)body + d] + acc[d] * a.ia.dt_kick;

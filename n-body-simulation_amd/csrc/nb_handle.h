@@ -16,6 +16,7 @@
 //   s->direct_set_split(nt)      the source split for nt targets per rank
 //   s->upload_extra(mass, radius), s->gather_extra(), s->after_load()   per-dimension arrays
 //   s->count_step()              a step was finished
+//   s->keeps_order_fresh()       the steps leave the bodies in the order of their own sort: no renewal
 #pragma once
 
 #include <algorithm>
@@ -600,7 +601,7 @@ int api_step(S *s, int nsteps)
         NB_TRY(step_local(s, 1));
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
-        if (++s->steps_in_order >= interval)
+        if (!s->keeps_order_fresh() && ++s->steps_in_order >= interval)
             NB_TRY(device_refresh(s));
     }
     return NB_OK;
@@ -672,7 +673,7 @@ int distributed_position_step(S *s)
     s->timer.mark(s->stream, StageTimer::STAGE_END);
     NB_TRY(step_finish(s));
     NB_TRY(collect_timing(s));
-    if (++s->steps_in_order >= refresh_interval(s->n, s->alg)) {
+    if (!s->keeps_order_fresh() && ++s->steps_in_order >= refresh_interval(s->n, s->alg)) {
         // every rank renews the order from the same positions; the new slices hold bodies other
         // ranks advanced so far, whose velocities come with one more all-gather
         NB_TRY(comm_all_gather_f64(s->comm, s->vel, S::D * s->chunk, s->stream));

@@ -27,6 +27,16 @@ struct nb_sim : nb::SimCore<2> {
     double2 *acc2d() const { return (double2 *)acc; }
 
     double2 *mass_radius = nullptr;  // Barnes-Hut: {mass, radius} per body (one gather instead of two)
+    // Barnes-Hut on one GPU: the second set of per-body arrays (with pos2).  Every step writes the bodies
+    // into it in the step's sorted order and the two sets change places (bh_step): the slots follow
+    // the bodies, the order never goes stale.
+    double *vel_b = nullptr, *acc_b = nullptr, *mass_b = nullptr, *radius_b = nullptr;
+    double2 *mass_radius_b = nullptr;
+    uint8_t *dyn_b = nullptr;
+    uint32_t *order_b = nullptr;
+    nb::BodyArrays2 body_arrays(bool other) const;
+    // the steps themselves keep the slots in the order of the tree: no renewal needed
+    bool keeps_order_fresh() const { return alg == NB_ALG_BARNES_HUT && world == 1 && vel_b != nullptr; }
 
     // direct sum
     float4 *posm[2] = {nullptr, nullptr};

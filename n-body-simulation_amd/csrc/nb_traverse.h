@@ -23,7 +23,7 @@
 //   child(aux), prune(aux)       child word (first child << 4 | ...; low four bits zero: no children) and the
 //                                float bits of the prune threshold (collision_th - cell diagonal)^2, or -1
 //   stage / staged accessors     what goes into the second staged word and how it is read back
-//   pos_ptr / load_acc / ...     FP64 state layout
+//   pos_ptr / load_acc / dest / carry / ...   FP64 state layout, and where a step leaves it
 #pragma once
 
 #include <type_traits>
@@ -544,20 +544,26 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
     }
     if (!valid)
         return;
+    // Where the body's state goes: its own slot, or -- in a step that leaves the bodies in this
+    // step's sorted order -- slot k of the other set of arrays (T::carry then moves what the step
+    // does not compute).
+    const uint32_t dst = T::dest(a, body, (uint32_t)k);
     double acc[DIM];
     if (dynamic) {
 #pragma unroll
         for (int d = 0; d < DIM; ++d)
             acc[d] = sum[d] * a.ia.acc_factor;
-        T::store_acc(a, body, acc);
+        T::store_acc(a, dst, acc);
     }
     // a static body keeps the acceleration it was given (calculateAcceleration, barnesHut.cpp:96-106)
     // and every body is advanced with its own velocity (barnesHut.cpp:108-123)
-    if (a.ia.do_integrate && (dynamic || !a.ia.static_fixed)) {
+    const bool advance = a.ia.do_integrate && (dynamic || !a.ia.static_fixed);
+    if (advance) {
         if (!dynamic)
             T::load_acc(a, body, acc);
-        T::integrate(a, body, acc);
+        T::integrate(a, body, dst, acc);
     }
+    T::carry(a, body, dst, dynamic, advance);
 }
 
 }  // namespace nb

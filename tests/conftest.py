@@ -75,6 +75,19 @@ def rel_err(a, ref):
     return out
 
 
+def conditioning(b, t, collision_th):
+    """sum |term| / |sum of terms| of body t's acceleration summed directly in FP64 over every body
+    outside the reference's cutoff (directSum.cpp:69-72).  A float evaluation of a sum with ratio c
+    is good to about c * 1e-7: bodies inside a dense core, whose neighbours within the cutoff do
+    not count and whose other neighbours pull in all directions, have ratios of 100 and more."""
+    d = b["pos"] - b["pos"][t]
+    r2 = (d * d).sum(axis=1)
+    r2[t] = np.inf
+    r2[np.sqrt(r2) <= b["radius"] + b["radius"][t] + collision_th] = np.inf
+    terms = d * (b["mass"] / (r2 * np.sqrt(r2)))[:, None]
+    return float(np.linalg.norm(terms, axis=1).sum() / np.linalg.norm(terms.sum(axis=0)))
+
+
 def sampled_targets(b, count, seed):
     """`count` dynamic bodies: half drawn uniformly, half the ones nearest to the most massive
     bodies (the densest part of the tree, where cells close to the cutoff are judged)."""

@@ -123,8 +123,9 @@ def test_native_rccl_world1_matches_plain_update(nb, oracle, alg, dims):
 
 @pytest.mark.parametrize("dims", [2, 3])
 def test_native_rccl_world1_renews_the_order_like_the_plain_run(nb, oracle, dims):
-    """nb_step_distributed crosses the Barnes-Hut order renewal (every 256 steps: one more all-gather,
-    of the velocities, then the renewal on the device) exactly as nb_step does."""
+    """nb_step_distributed moves the bodies between slots exactly as nb_step does: 3-D crosses the
+    Barnes-Hut order renewal (every 256 steps: one more all-gather, of the velocities, then the renewal on
+    the device); a 2-D run on one GPU leaves the bodies in the order of every step's own sort."""
     n = 2000
     b = oracle.scenario(0, n, 6) if dims == 2 else oracle.scenario3(0, n, 6, thickness=5.0e10)
     Sim = nb.NBodySim if dims == 2 else nb.NBodySim3

@@ -89,7 +89,10 @@ def test_static_entry_point_matches_the_handle_path_twice_in_a_row(nb):
             a.compute_accel_static(pos_d.data_ptr(), acc_d.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         torch.cuda.synchronize()
         assert free_device_bytes(hip) == before
-        assert np.array_equal(acc_d.cpu().numpy(), ref_big)
+        # (the handle has stepped since ref_big was made, and a 2-D Barnes-Hut step leaves the bodies in other
+        # slots: bodies sharing a leaf are summed in another order)
+        got = acc_d.cpu().numpy()
+        assert (np.linalg.norm(got[dyn] - ref_big[dyn], axis=1) / np.linalg.norm(ref_big[dyn], axis=1)).max() <= 1e-6
 
 
 def test_static_entry_point_rejects_what_it_cannot_do(nb):
