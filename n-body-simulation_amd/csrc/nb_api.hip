@@ -52,7 +52,7 @@ BhStepArgs bh_args(nb_sim *s, int do_integrate)
     a.bucket_depth = s->p.bucket_depth;
     a.collect_stats = s->collect_stats;
     a.from = s->body_arrays(false);
-    if (do_integrate && s->keeps_order_fresh())
+    if (do_integrate && s->keeps_order_fresh() && s->bh_steps % s->resort_every() == 0)
         a.to = s->body_arrays(true);
     return a;
 }
@@ -146,6 +146,8 @@ int nb_sim::bh_step(int do_integrate)
     timer.mark(stream, 5);
     NB_TRY(bh_force(stream, bh, a));
     timer.mark(stream, 6);
+    if (do_integrate)
+        bh_steps += 1;
     if (a.to.pos) {
         // the step left the bodies in the other set of arrays, in the order of its tree
         std::swap(pos, pos2);
@@ -222,7 +224,11 @@ int nb_sim::upload_extra(const double *mass_h, const double *radius_h)
 int nb_sim::gather_extra() { return refresh_gather(stream, rb, mass_radius, sizeof(double2), n); }
 
 // The key depth the first steps will find, so that their launches are sized right from the start.
-int nb_sim::after_load() { return alg == NB_ALG_BARNES_HUT ? bh_prime(stream, bh, bh_args(this, 0)) : (int)NB_OK; }
+int nb_sim::after_load()
+{
+    bh_steps = 0;
+    return alg == NB_ALG_BARNES_HUT ? bh_prime(stream, bh, bh_args(this, 0)) : (int)NB_OK;
+}
 
 extern "C" {
 

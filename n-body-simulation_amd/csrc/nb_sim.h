@@ -35,6 +35,13 @@ struct nb_sim : nb::SimCore<2> {
     uint8_t *dyn_b = nullptr;
     uint32_t *order_b = nullptr;
     nb::BodyArrays2 body_arrays(bool other) const;
+    long bh_steps = 0;  // Barnes-Hut steps taken since the bodies were set
+    // Steps between two that re-order the bodies.  The re-ordering rides in the traversal's shadow while
+    // the per-body arrays stay near the last-level cache (N = 5 M: +0.8 % on the traversal, and the
+    // order goes stale within five steps once the bodies mix: every step); at N = 50 M its 65 bytes
+    // per body show (traversal 4.24 -> 4.54 ms): every eighth step.  By N alone, so that a run is
+    // the same whenever it is repeated.
+    int resort_every() const { return n > (1 << 24) ? 8 : 1; }
     // the steps themselves keep the slots in the order of the tree: no renewal needed
     bool keeps_order_fresh() const { return alg == NB_ALG_BARNES_HUT && world == 1 && vel_b != nullptr; }
 
