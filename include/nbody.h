@@ -143,9 +143,10 @@ int nb_set_stream(nb_sim *sim, void *hip_stream);
 
 /* ---- multi-GPU: one process per GPU, every process holds all n bodies ---- */
 
-/* Bodies are held in "exchange order": sorted once, when they are set, by a Morton code of
- * their initial positions (NB_DBG_ORDER gives the caller index of each slot), so that an
- * index range is a compact patch of space.  This process integrates only the bodies in slots
+/* Bodies are held in "exchange order": sorted when they are set by a Morton code of their
+ * positions (NB_DBG_ORDER gives the caller index of each slot), so that an index range is a
+ * compact patch of space; the order is renewed as described at nb_refresh_order, and a partitioned
+ * simulation changes it only there.  This process integrates only the bodies in slots
  * [rank*chunk, min(n,(rank+1)*chunk)), chunk = ceil(n / world).
  * Must be called after the bodies were set and before the first step. */
 int nb_set_partition(nb_sim *sim, int rank, int world);
@@ -268,7 +269,11 @@ int nb_stage_ms(nb_sim *sim, float *out, int count);
  * the state through its per-step sort, whose permutation drifts away from the identity as the bodies
  * mix.  nb_step and nb_step_distributed do it by themselves, every max(32, min(4096, 1.4e11 / n^2))
  * steps for the direct sum and every 256 steps for Barnes-Hut (not while cells are exchanged: a rank then
- * holds only its own bodies).  The reference keeps bodies in creation order and has nothing of the kind.
+ * holds only its own bodies).  A 2-D Barnes-Hut simulation on one GPU needs none of that: each of its
+ * steps (every eighth above 2^24 bodies) leaves the bodies in the order of the step's own sort, in a
+ * second set of per-body arrays that then changes places with the first (85 bytes per body more; made
+ * with NB_KEEP_SLOTS set in the environment a handle does without and renews every 256 steps, a
+ * switch for comparisons).  The reference keeps bodies in creation order and has nothing of the kind.
  * A partitioned simulation driven through nb_step_local / nb_step_finish may call it between
  * steps on EVERY rank, after all-gathering the velocity buffer the way the position buffer is
  * gathered (nb_velocity_buffer: same layout): every rank then derives the same order, and the
@@ -292,9 +297,9 @@ int nb_diagnostics(nb_sim *sim, double *out, int count);
  * nb_set_bodies -- written to acc_xy (device memory, n records {ax, ay}, same order; a static body
  * gets the acceleration the handle holds for it, as nb_read_bodies would return).  Nothing of the
  * handle is changed, and its positions and velocities are not read; what IS read are the arrays
- * the handle's own steps rewrite on the handle's stream -- the exchange order (renewed by
- * nb_refresh_order and every 256 steps by nb_step), the stored accelerations, masses, radii and
- * dynamic flags.  This call orders nothing between the two streams (an event wait would not be
+ * the handle's own steps rewrite on the handle's stream -- the exchange order (see
+ * nb_refresh_order: a one-GPU handle's steps change it every time), the stored accelerations, masses,
+ * radii and dynamic flags.  This call orders nothing between the two streams (an event wait would not be
  * capturable): when hip_stream is not the handle's stream, call nb_sync after the last nb_step /
  * nb_refresh_order / nb_set_bodies before calling this, and let this call's work finish before
  * the next of those.
