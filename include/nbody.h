@@ -269,8 +269,9 @@ int nb_stage_ms(nb_sim *sim, float *out, int count);
  * the state through its per-step sort, whose permutation drifts away from the identity as the bodies
  * mix.  nb_step and nb_step_distributed do it by themselves, every max(32, min(4096, 1.4e11 / n^2))
  * steps for the direct sum and every 256 steps for Barnes-Hut (not while cells are exchanged: a rank then
- * holds only its own bodies).  A 2-D Barnes-Hut simulation on one GPU needs none of that: each of its
- * steps (every eighth above 2^24 bodies) leaves the bodies in the order of the step's own sort, in a
+ * holds only its own bodies).  A 2-D Barnes-Hut simulation on one GPU needs none of that: each step of
+ * its nb_step (every eighth above 2^24 bodies; not a step driven through nb_step_local, whose caller
+ * holds the exchange buffer's address) leaves the bodies in the order of the step's own sort, in a
  * second set of per-body arrays that then changes places with the first (85 bytes per body more; made
  * with NB_KEEP_SLOTS set in the environment a handle does without and renews every 256 steps, a
  * switch for comparisons).  The reference keeps bodies in creation order and has nothing of the kind.

@@ -52,7 +52,8 @@ BhStepArgs bh_args(nb_sim *s, int do_integrate)
     a.bucket_depth = s->p.bucket_depth;
     a.collect_stats = s->collect_stats;
     a.from = s->body_arrays(false);
-    if (do_integrate && s->keeps_order_fresh() && s->bh_steps % s->resort_every() == 0)
+    // (not in a step the caller drives through nb_step_local: the exchange buffer it was given stays the positions)
+    if (do_integrate && s->own_loop && s->keeps_order_fresh() && s->bh_steps % s->resort_every() == 0)
         a.to = s->body_arrays(true);
     return a;
 }

@@ -65,6 +65,7 @@ struct SimCore {
     size_t chunk = 0;
     int t0 = 0, t1 = 0;
     bool mid_step = false;
+    bool own_loop = false;  // the step in flight is one of nb_step / nb_step_distributed (which may move bodies between slots)
     Comm *comm = nullptr;  // RCCL communicator of the comm_init entry point (null: none)
     size_t part_cap = 0;   // direct sum: partial sums allocated
 
@@ -598,7 +599,10 @@ int api_step(S *s, int nsteps)
         return fail(NB_ERR_STATE, fn<S>("step: a split step is in flight"));
     const long interval = refresh_interval(s->n, s->alg);
     for (int k = 0; k < nsteps; ++k) {
-        NB_TRY(step_local(s, 1));
+        s->own_loop = true;
+        const int rc = step_local(s, 1);
+        s->own_loop = false;
+        NB_TRY(rc);
         NB_TRY(step_finish(s));
         NB_TRY(collect_timing(s));
         if (!s->keeps_order_fresh() && ++s->steps_in_order >= interval)
@@ -665,7 +669,10 @@ int check_distributed(S *s, int nsteps)
 template <class S>
 int distributed_position_step(S *s)
 {
-    NB_TRY(step_local(s, 1));
+    s->own_loop = true;
+    const int rc = step_local(s, 1);
+    s->own_loop = false;
+    NB_TRY(rc);
     // the new positions of every rank's slice, in place, ordered on the stream with the kernels
     // before and after: the host does not wait
     double *buf = s->alg == NB_ALG_DIRECT ? s->pos2 : s->pos;

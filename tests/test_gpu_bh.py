@@ -7,8 +7,6 @@ theta (observed ~1e-6: every body accepts exactly the cells the reference accept
 remaining difference is FP32 force rounding); trajectories after 100 steps within 1e-5 of the
 system's extent.
 """
-import os
-
 import numpy as np
 import pytest
 
@@ -708,10 +706,9 @@ def test_long_tree_run_keeps_its_slots_in_the_order_of_the_tree(nb, oracle, dims
     """The per-step sort's permutation drifts away from the identity as bodies mix, and the leaf pass and
     the traversal gather through it.  2-D: every step of a one-GPU run leaves the bodies in the order of
     its own sort (the traversal writes body k of the sorted order to slot k of a second set of arrays);
-    3-D: nb3_step renews the order every 256 steps.  300 steps through nb_step against 300 split steps
-    of a handle whose bodies keep their slots (2-D: made with NB_KEEP_SLOTS in the environment, the
-    library's switch for exactly this comparison; 3-D: split steps never renew): the same run up to
-    FP32 summation order, and the slot -> body map has changed on the way."""
+    3-D: nb3_step renews the order every 256 steps.  300 steps through nb_step against 300 split steps,
+    which leave every body in its slot: the same run up to FP32 summation order, and the slot -> body
+    map has changed on the way."""
     n = 3000
     if dims == 2:
         b = oracle.scenario(0, n, 8)
@@ -719,12 +716,7 @@ def test_long_tree_run_keeps_its_slots_in_the_order_of_the_tree(nb, oracle, dims
     else:
         b = oracle.scenario3(0, n, 8, thickness=4.0e10)
         make = lambda: nb.NBodySim3(n, nb.BARNES_HUT)  # noqa: E731
-    os.environ["NB_KEEP_SLOTS"] = "1"
-    try:
-        plain = make()
-    finally:
-        del os.environ["NB_KEEP_SLOTS"]
-    with make() as auto, plain:
+    with make() as auto, make() as plain:
         auto.set_bodies(b)
         plain.set_bodies(b)
         first = auto.order().copy()

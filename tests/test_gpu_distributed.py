@@ -56,8 +56,15 @@ def test_distributed_stepper_world1_matches_plain_update(nb, oracle, nccl_group,
         a = part.read_bodies()
         ref = plain.read_bodies()
         assert np.array_equal(t.cpu().numpy(), a["pos"][part.order()])
-    assert np.array_equal(a["pos"], ref["pos"])
-    assert np.array_equal(a["vel"], ref["vel"])
+    if alg == nb.DIRECT:
+        assert np.array_equal(a["pos"], ref["pos"])
+        assert np.array_equal(a["vel"], ref["vel"])
+    else:
+        # nb_step leaves the bodies of a one-GPU 2-D Barnes-Hut run in the order of every step's sort, split
+        # steps leave them in their slots: bodies of one leaf are summed, and grouped for the traversal,
+        # in another order (FP32 summation noise)
+        assert np.abs(a["pos"] - ref["pos"]).max() <= 1e-9 * np.abs(ref["pos"]).max()
+        assert np.abs(a["vel"] - ref["vel"]).max() <= 1e-6 * np.abs(ref["vel"]).max()
 
 
 @pytest.mark.parametrize("alg", [0, 1])
