@@ -1013,14 +1013,22 @@ __device__ __forceinline__ PyrCell pyr_combine(const ComArgs &a, const PyrCell *
 // builds levels r..L under it bottom-up in LDS (at most 4 levels below the block's cell: 341
 // cells); k_pyr_top then builds levels r-1..0 in one block, also in LDS.  With L = 11 the cut is at
 // level 7, 16384 cells, too many for one block: k_pyr_mid takes levels 6..3 in between, again a
-// block per cell of its top level, and k_pyr_top starts from level pyr_top_from(L) = 3.
+// block per cell of its top level, and k_pyr_top starts from level pyr_top_from(L) = 3 (L = 10: levels
+// 5..2 and 2, when the host launched k_pyr_mid for the step).
 __host__ __device__ constexpr int pyr_split(int L) { return L > 4 ? L - 4 : 0; }
-__host__ __device__ constexpr int pyr_top_from(int L) { return L > PYR_MAX_LEVEL ? pyr_split(L) - 4 : pyr_split(L); }
+// (k_pyr_mid also takes a pyramid of PYR_MID_FROM levels when the host launched it: its 4096 cells of
+// level 6 otherwise pass through one block's staging area, 32 us against 8 + 6)
+constexpr int PYR_MID_FROM = 10;
+__host__ __device__ constexpr int pyr_top_from(int L, bool mid = true)
+{
+    return (mid && L >= PYR_MID_FROM) ? pyr_split(L) - 4 : pyr_split(L);
+}
 constexpr int PYR_SUB_CELLS = 341;   // 1 + 4 + 16 + 64 + 256
 constexpr int PYR_TOP_CELLS = 1365;  // levels 0..5 ...
 constexpr int PYR_TOP_STAGE = 512;   // ... and, when r = 6, the level-6 cells in batches of this many
-static_assert(pyr_top_from(PYR_MAX_LEVEL) <= 6 && pyr_top_from(PYR_DEEP_LEVEL) <= 6 && pyr_top_from(PYR_DEEP_LEVEL) >= 0,
-              "k_pyr_top stages at most one level beyond the six it holds");
+static_assert(pyr_top_from(PYR_MAX_LEVEL, false) <= 6 && pyr_top_from(PYR_DEEP_LEVEL) <= 6 && pyr_top_from(PYR_MID_FROM) >= 0 &&
+                  PYR_MID_FROM <= PYR_MAX_LEVEL,
+              "k_pyr_top stages at most one level beyond the six it holds; deeper pyramids come with k_pyr_mid");
 
 // The sums of pyr_short_sums / pyr_long_sums for the cell of every thread of a 256-thread block
 // (all threads call; range = {first, end} of the thread's cell, {0, 0} for none).  Long runs are
@@ -1212,16 +1220,16 @@ __global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, co
     }
 }
 
-// Levels r - 1 .. r - 4 of a pyramid deeper than PYR_MAX_LEVEL (r = pyr_split(L)): one block per
+// Levels r - 1 .. r - 4 of a pyramid of PYR_MID_FROM levels or more (r = pyr_split(L)): one block per
 // cell of level r - 4 reads the 256 cells of level r under it, which k_pyr_sub stored, and builds
-// the four levels above them in LDS.  Launched whenever the host expects such keys; a step whose
-// keys stop earlier has nothing for it to do.
+// the four levels above them in LDS.  Launched whenever the host expects such keys (k_pyr_top is told);
+// a step whose keys stop earlier has nothing for it to do.
 __global__ __launch_bounds__(256) void k_pyr_mid(ComArgs a, uint4 *node_meta)
 {
     if (a.cut[3] == 0u)
         return;
     const int L = (int)a.cut[4];
-    if (L <= PYR_MAX_LEVEL)
+    if (L < PYR_MID_FROM)
         return;
     __shared__ PyrCell cells[PYR_SUB_CELLS];  // levels r - 4 .. r of the block's cell
     const int r = pyr_split(L), r2 = pyr_top_from(L);
@@ -1254,7 +1262,8 @@ constexpr int COM_TOP_LEVELS = 5;  // levels 0..4: at most 341 cells
 // instead: slow, complete, and rare -- the host learns the new depth from this very step.
 __global__ __launch_bounds__(256) void k_pyr_top(ComArgs a, uint4 *node_meta, uint32_t *level_start,
                                                  unsigned long long *counters, const uint64_t *keys, Split<2> *split,
-                                                 uint32_t *bsum, int n, uint32_t *levels_host, const uint32_t *chunk_info)
+                                                 uint32_t *bsum, int n, uint32_t *levels_host, const uint32_t *chunk_info,
+                                                 int mid_launched)
 {
     __shared__ PyrCell cells[PYR_TOP_CELLS + PYR_TOP_STAGE];  // levels 0..min(r, 5), then the staging area
     if (a.cut[3] == 0u) {
@@ -1291,7 +1300,7 @@ __global__ __launch_bounds__(256) void k_pyr_top(ComArgs a, uint4 *node_meta, ui
         return;
     }
     const int L = (int)a.cut[4];
-    const int r = pyr_top_from(L);  // the deepest level already stored (by k_pyr_sub or k_pyr_mid)
+    const int r = pyr_top_from(L, mid_launched != 0);  // the deepest level already stored (by k_pyr_sub or k_pyr_mid)
     const double width0 = a.box[2] - a.box[0];
     int held = r;  // the level held in LDS from which the sweep goes on
     if (r > 5) {
@@ -1348,10 +1357,12 @@ int bh_com(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
         const int deepest = (int)(hint <= (uint32_t)b.pyr_max ? hint : (uint32_t)b.pyr_max);
         const dim3 grid(1u << (2 * pyr_split(deepest)));
         hipLaunchKernelGGL(k_pyr_sub<false>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range, (const double *)nullptr);
-        if (b.pyr_levels > PYR_MAX_LEVEL)
-            hipLaunchKernelGGL(k_pyr_mid, dim3(1u << (2 * pyr_top_from(PYR_DEEP_LEVEL))), dim3(256), 0, s, c, b.node_meta);
+        // (keys of PYR_MID_FROM levels that the hint did not announce still pass through k_pyr_top's staging area)
+        const bool mid = b.pyr_levels > PYR_MAX_LEVEL || (hint >= (uint32_t)PYR_MID_FROM && hint <= (uint32_t)b.pyr_max);
+        if (mid)
+            hipLaunchKernelGGL(k_pyr_mid, dim3(1u << (2 * pyr_top_from(deepest))), dim3(256), 0, s, c, b.node_meta);
         hipLaunchKernelGGL(k_pyr_top, dim3(1), dim3(256), 0, s, c, b.node_meta, b.level_start, b.counters, b.keys[b.sorted],
-                           (Split<2> *)b.split, b.bsum, a.n, b.levels_host, b.chunk_info);
+                           (Split<2> *)b.split, b.bsum, a.n, b.levels_host, b.chunk_info, mid ? 1 : 0);
         NB_HIP(hipGetLastError());
         return NB_OK;
     }
@@ -1491,7 +1502,7 @@ int bh_cells_end(hipStream_t s, BhBuffers &b, const BhStepArgs &a, int cells_lev
     const dim3 grid(1u << (2 * pyr_split(cells_levels)));
     hipLaunchKernelGGL(k_pyr_sub<true>, grid, dim3(256), 0, s, c, b.node_meta, b.pc_range, b.agg);
     hipLaunchKernelGGL(k_pyr_top, dim3(1), dim3(256), 0, s, c, b.node_meta, b.level_start, b.counters, b.keys[0],
-                       (Split<2> *)b.split, b.bsum, a.n, b.levels_host, b.chunk_info);
+                       (Split<2> *)b.split, b.bsum, a.n, b.levels_host, b.chunk_info, 0);
     NB_HIP(hipGetLastError());
     return NB_OK;
 }
