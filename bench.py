@@ -526,7 +526,10 @@ def main():
                 "slots_per_lds_instruction": census["slots_per_lds_instruction"],
                 "source": "SQ_INSTS_VALU / SQ_INSTS_LDS per launch from the rocprofv3 --pmc pass recorded in profiles/traffic.json "
                           "(%s); slot weights and the issue rate (v_fma_f32: 58 T lane-ops/s) measured by bin/microbench; "
-                          "not counters of this run" % got.get("workload", "")}
+                          "not counters of this run" % got.get("workload", ""),
+                "accuracy": "the slot prices are single numbers fitted to microbenchmarks (an LDS read 3.3 vector slots, "
+                            "whatever else the SIMD issues beside it): good to about 5 %, so a launch that stalls on "
+                            "nothing can read slightly above 1"}
     roofline = {"bound": "hbm", "kernel": "k_bh_force", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "l2_hit_rate": l2_hit, "kernel_ms": force_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,

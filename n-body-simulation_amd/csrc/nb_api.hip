@@ -235,7 +235,7 @@ extern "C" {
 
 const char *nb_last_error(void) { return g_error.c_str(); }
 
-const char *nb_version(void) { return "nbody_hip 0.2 (gfx950)"; }
+const char *nb_version(void) { return "nbody_hip 0.3 (gfx950)"; }
 
 int nb_create(const nb_params *params, int n, int alg, nb_sim **out) { return api_create(params, n, alg, out); }
 
