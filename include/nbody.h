@@ -155,9 +155,10 @@ int nb_set_partition(nb_sim *sim, int rank, int world);
  * (x, y), record k*chunk+i being body i of rank k's slice.  After
  * nb_step_local() the own slice holds the new positions; the host all-gathers
  * the buffer in place (every rank contributes chunk records at offset
- * rank*chunk) and then calls nb_step_finish().  The address stays what it is across
- * nb_step_local / nb_step_finish; nb_step of an unpartitioned 2-D Barnes-Hut handle
- * alternates between two sets of arrays (see nb_refresh_order): ask again after it. */
+ * rank*chunk) and then calls nb_step_finish().  Ask for the address when it is needed,
+ * i.e. between nb_step_local and nb_step_finish: the direct sum alternates between two
+ * position buffers, and so does nb_step of an unpartitioned 2-D Barnes-Hut handle (see
+ * nb_refresh_order). */
 int nb_exchange_buffer(nb_sim *sim, void **device_ptr, size_t *chunk_records, size_t *record_bytes);
 int nb_step_local(nb_sim *sim);
 int nb_step_finish(nb_sim *sim);
