@@ -1034,10 +1034,12 @@ static_assert(pyr_top_from(PYR_MAX_LEVEL, false) <= 6 && pyr_top_from(PYR_DEEP_L
 // (all threads call; range = {first, end} of the thread's cell, {0, 0} for none).  Long runs are
 // dealt to the block's four waves: they cluster in a few neighbouring cells, i.e. in one wave's
 // threads.
-__device__ __forceinline__ void block_leaf_sums(const double *leaf_sum, uint2 range, double (&sums)[4])
+// scratch: LEAF_SUMS_SCRATCH bytes of LDS, 16-byte aligned, free again when the call returns.
+constexpr int LEAF_SUMS_SCRATCH = 256 * (int)(sizeof(uint4) + 4 * sizeof(double));
+__device__ __forceinline__ void block_leaf_sums(const double *leaf_sum, uint2 range, double (&sums)[4], void *scratch)
 {
-    __shared__ uint4 long_range[256];  // cells whose bodies span many chunks: first, end, owning thread
-    __shared__ double long_sum[256][4];
+    uint4 *long_range = (uint4 *)scratch;  // [256] cells whose bodies span many chunks: first, end, owning thread
+    double(*long_sum)[4] = (double(*)[4])((char *)scratch + 256 * sizeof(uint4));  // [256][4]
     __shared__ int nlong;
     sums[0] = sums[1] = sums[2] = sums[3] = 0.0;
     if (threadIdx.x == 0)
@@ -1082,13 +1084,14 @@ constexpr int AGG_DOUBLES = 8;
 
 __global__ __launch_bounds__(256) void k_agg_fill(ComArgs a, const uint2 *pc_range, double *agg)
 {
+    __shared__ __attribute__((aligned(16))) char scratch[LEAF_SUMS_SCRATCH];
     const uint32_t ncell = 1u << (2 * (int)a.cut[1]);
     for (uint32_t base = blockIdx.x * 256u; base < ncell; base += gridDim.x * 256u) {  // whole blocks go round
         const uint32_t c = base + threadIdx.x;
         const uint2 range = c < ncell ? pc_range[c] : make_uint2(0u, 0u);
         const uint32_t count = range.y > range.x ? range.y - range.x : 0u;
         double sums[4];
-        block_leaf_sums(a.leaf_sum, range, sums);
+        block_leaf_sums(a.leaf_sum, range, sums, scratch);
         double rec[AGG_DOUBLES] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (count == 1u) {
             const uint32_t o = a.idx[range.x];
@@ -1157,8 +1160,11 @@ __device__ __forceinline__ PyrCell pyr_leaf_from_cells(const ComArgs &a, const d
 
 // Levels r .. L: one block per cell of level r.  CELLS: the leaves come from the exchanged cell
 // records (agg) instead of this GPU's own sorted bodies (pc_range, leaf sums).
+#ifndef NB_PYR_SUB_WAVES
+#define NB_PYR_SUB_WAVES 5  // waves per SIMD the kernel is compiled for: five blocks per CU instead of four
+#endif
 template <bool CELLS>
-__global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, const uint2 *pc_range, const double *agg)
+__global__ __launch_bounds__(256, NB_PYR_SUB_WAVES) void k_pyr_sub(ComArgs a, uint4 *node_meta, const uint2 *pc_range, const double *agg)
 {
     if (a.cut[3] == 0u)
         return;
@@ -1196,7 +1202,9 @@ __global__ __launch_bounds__(256) void k_pyr_sub(ComArgs a, uint4 *node_meta, co
             } else {
                 const uint2 range = mine ? pc_range[c] : make_uint2(0u, 0u);
                 double sums[4];
-                block_leaf_sums(a.leaf_sum, range, sums);
+                // (the long runs' scratch lies where this round's leaves go once their sums are known)
+                static_assert(LEAF_SUMS_SCRATCH <= 256 * (int)sizeof(PyrCell), "the scratch fits under one round of leaves");
+                block_leaf_sums(a.leaf_sum, range, sums, (void *)&cells[pyr_offset(sub) + t0]);
                 leaf = pyr_leaf(a, range.x, range.y, L, width0, sums);
             }
             if (mine) {
