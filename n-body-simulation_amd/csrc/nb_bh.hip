@@ -271,8 +271,13 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // ------------------------------------------------------------------ 2 keys
 
-// Digit of level l (0 = the root's split) occupies bits [61-2l, 60-2l]:
-// 2*(below the y midpoint) + (right of the x midpoint), i.e. TL=0, TR=1, BL=2, BR=3.
+// Hilbert curve through the four quadrants of a cell {TL, TR, BL, BR} = {0, 1, 2, 3}: entry
+// 4 * orientation + quadrant of HILBERT_DIGIT is the quadrant's position along the curve, of HILBERT_NEXT the
+// orientation inside that quadrant (orientation = swap x and y | invert both << 1, 0 at the root).
+constexpr uint32_t HILBERT_DIGIT = 0x1e36b49cu, HILBERT_NEXT = 0xb3da640du;
+
+// Digit of level l (0 = the root's split) occupies bits [61-2l, 60-2l]: the position along the cell's
+// Hilbert curve of the quadrant 2*(below the y midpoint) + (right of the x midpoint), TL=0, TR=1, BL=2, BR=3.
 // Only the first cut[1] digits are computed, the rest of the key is zero: bodies of one cell of
 // that level then share a key and end up in one leaf.  The keys go to the buffer the first sort
 // pass that has work (cut[2]) reads from (see sort_pairs).
@@ -294,6 +299,7 @@ __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const d
     double tlx = box[0], tly = box[1], brx = box[2], bry = box[3];
     const double2 p = pos[i];
     uint64_t k = 0;
+    uint32_t curve = 0u;  // orientation of the Hilbert curve inside the current cell
 #pragma unroll 1
     for (int l = 0; l < levels; ++l) {
         const double mx = (tlx + brx) / 2.0, my = (tly + bry) / 2.0;
@@ -303,7 +309,14 @@ __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const d
         brx = right ? brx : mx;
         tly = below ? my : tly;
         bry = below ? bry : my;
-        k = (k << 2) | ((uint64_t)below << 1) | (uint64_t)right;
+        // The quadrant (the reference's decision) enters the key as the position of that quadrant along
+        // a Hilbert curve through the cell: the cells of every level are still contiguous ranges of the
+        // sorted bodies, as the tree needs them, and consecutive cells are always neighbours in space
+        // (in Z order a quarter of them are not), so the 64 consecutive bodies of a traversal wave
+        // fill a tighter box.  Two tables of 16 two-bit entries, indexed by orientation and quadrant.
+        const uint32_t at = 2u * (4u * curve + (((uint32_t)below << 1) | (uint32_t)right));
+        k = (k << 2) | (uint64_t)((HILBERT_DIGIT >> at) & 3u);
+        curve = (HILBERT_NEXT >> at) & 3u;
     }
     const bool odd = cut[2] & 1u;
     const uint64_t key = levels > 0 ? k << (2 * (BH_KEY_LEVELS - levels)) : 0ull;

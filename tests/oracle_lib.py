@@ -280,6 +280,22 @@ class Oracle:
         self.lib.orc3_morton_keys(len(b), _ptr(b), _ptr(box), _ptr(keys))
         return keys
 
+    def tree_keys(self, b, box):
+        """The keys the library sorts by: the reference's quadrant path of every body (morton_keys), each
+        digit replaced by the quadrant's position along a Hilbert curve through its cell (the same
+        two tables as the library's k_keys: entry 4 * orientation + quadrant).  A bijection on paths:
+        equal keys mean equal quadrant decisions at every level."""
+        m = self.morton_keys(b, box)
+        digit_of, next_of = 0x1E36B49C, 0xB3DA640D
+        h = np.zeros(len(m), dtype=np.uint64)
+        curve = np.zeros(len(m), dtype=np.uint64)
+        for level in range(31):
+            q = (m >> np.uint64(60 - 2 * level)) & np.uint64(3)
+            at = np.uint64(2) * (np.uint64(4) * curve + q)
+            h = (h << np.uint64(2)) | ((np.uint64(digit_of) >> at) & np.uint64(3))
+            curve = (np.uint64(next_of) >> at) & np.uint64(3)
+        return h
+
     def morton_keys(self, b, box):
         keys = np.zeros(len(b), dtype=np.uint64)
         box = np.ascontiguousarray(box, dtype=np.float64)

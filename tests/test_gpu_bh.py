@@ -83,7 +83,7 @@ def test_bbox_keys_sort_are_bit_exact(nb, oracle, name):
     box = sim.debug(nb.DBG_BBOX, np.float64, 4)
     assert np.array_equal(box, oracle.bh_bbox(b))
     keys = sim.debug(nb.DBG_KEYS, np.uint64, len(b))
-    ref_keys, levels = cut_keys(nb, sim, oracle.morton_keys(b, box))
+    ref_keys, levels = cut_keys(nb, sim, oracle.tree_keys(b, box))
     assert 6 <= levels <= 12  # the reference's constants: cutoff 1e10 in a ~1e12 box, theta 0.5
     assert np.array_equal(keys, ref_keys)
     order = np.argsort(ref_keys, kind="stable")
@@ -99,7 +99,7 @@ def test_radix_sort_matches_cpu_stable_sort_large(nb, oracle, n):
     b = exchange_bodies(sim, b)
     box = sim.debug(nb.DBG_BBOX, np.float64, 4)
     assert np.array_equal(box, oracle.bh_bbox(b))
-    ref_keys, _ = cut_keys(nb, sim, oracle.morton_keys(b, box))
+    ref_keys, _ = cut_keys(nb, sim, oracle.tree_keys(b, box))
     order = np.argsort(ref_keys, kind="stable")
     assert np.array_equal(sim.debug(nb.DBG_SORTED_IDX, np.uint32, n), order.astype(np.uint32))
     assert np.array_equal(sim.debug(nb.DBG_SORTED_KEYS, np.uint64, n), ref_keys[order])
@@ -754,7 +754,7 @@ def test_sort_is_finished_when_the_keys_outgrow_the_launched_passes(nb, oracle, 
             state = exchange_bodies(sim, sim.read_bodies())
             box = sim.debug(nb.DBG_BBOX, np.float64, 4)
             assert np.array_equal(box, oracle.bh_bbox(state))
-            ref_keys, levels = cut_keys(nb, sim, oracle.morton_keys(state, box))
+            ref_keys, levels = cut_keys(nb, sim, oracle.tree_keys(state, box))
             order = np.argsort(ref_keys, kind="stable")
             assert np.array_equal(sim.debug(nb.DBG_SORTED_KEYS, np.uint64, n), ref_keys[order])
             assert np.array_equal(sim.debug(nb.DBG_SORTED_IDX, np.uint32, n), order.astype(np.uint32))
