@@ -274,6 +274,42 @@ class Oracle:
             raise ValueError("coincident bodies")
         return b
 
+    def tree_keys3(self, b, box):
+        """The keys the octree pipeline sorts by: the octant path of every body (morton_keys3) with the
+        octants' positions along a Hilbert curve as digits -- Skilling's transform of the three bit
+        strings, as in the library's k_keys3.  A bijection on paths whose every digit depends on the
+        path down to its own level only: cut at any level it is that level's key."""
+        m = self.morton_keys3(b, box)
+        levels = 20
+        c = [np.zeros(len(m), dtype=np.uint64) for _ in range(3)]
+        for level in range(levels):
+            digit = (m >> np.uint64(62 - 3 * (level + 1))) & np.uint64(7)
+            for d in range(3):  # digit = z << 2 | y << 1 | x
+                c[d] = (c[d] << np.uint64(1)) | ((digit >> np.uint64(d)) & np.uint64(1))
+        top = 1 << (levels - 1)
+        q = top
+        while q > 1:
+            low = np.uint64(q - 1)
+            for d in range(3):
+                hit = (c[d] & np.uint64(q)) != 0
+                t = np.where(hit, np.uint64(0), (c[0] ^ c[d]) & low)
+                c[0] = np.where(hit, c[0] ^ low, c[0] ^ t)
+                c[d] = np.where(hit, c[d], c[d] ^ t) if d else c[0]
+            q >>= 1
+        c[1] = c[1] ^ c[0]
+        c[2] = c[2] ^ c[1]
+        t = np.zeros(len(m), dtype=np.uint64)
+        q = top
+        while q > 1:
+            t = np.where((c[2] & np.uint64(q)) != 0, t ^ np.uint64(q - 1), t)
+            q >>= 1
+        c = [v ^ t for v in c]
+        k = np.zeros(len(m), dtype=np.uint64)
+        for level in range(levels - 1, -1, -1):
+            sh = np.uint64(level)
+            k = (k << np.uint64(3)) | (((c[0] >> sh) & np.uint64(1)) << np.uint64(2)) | (((c[1] >> sh) & np.uint64(1)) << np.uint64(1)) | ((c[2] >> sh) & np.uint64(1))
+        return k << np.uint64(2)
+
     def morton_keys3(self, b, box):
         keys = np.zeros(len(b), dtype=np.uint64)
         box = np.ascontiguousarray(box, dtype=np.float64)

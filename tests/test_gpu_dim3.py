@@ -107,7 +107,7 @@ def test_octree_invariants_and_keys(nb, oracle):
     assert np.array_equal(box, oracle.bh_bbox3(b))
     # keys: the oracle's octant paths, cut to the levels the device kept, sorted stably
     levels = int(cut[1])
-    full = oracle.morton_keys3(b, box)[order]
+    full = oracle.tree_keys3(b, box)[order]
     keep = np.uint64(((1 << (3 * levels)) - 1) << (62 - 3 * levels)) if levels else np.uint64(0)
     expect = full & keep
     perm = np.argsort(expect, kind="stable")
