@@ -271,11 +271,6 @@ int bh_bbox(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 
 // ------------------------------------------------------------------ 2 keys
 
-// Hilbert curve through the four quadrants of a cell {TL, TR, BL, BR} = {0, 1, 2, 3}: entry
-// 4 * orientation + quadrant of HILBERT_DIGIT is the quadrant's position along the curve, of HILBERT_NEXT the
-// orientation inside that quadrant (orientation = swap x and y | invert both << 1, 0 at the root).
-constexpr uint32_t HILBERT_DIGIT = 0x1e36b49cu, HILBERT_NEXT = 0xb3da640du;
-
 // Digit of level l (0 = the root's split) occupies bits [61-2l, 60-2l]: the position along the cell's
 // Hilbert curve of the quadrant 2*(below the y midpoint) + (right of the x midpoint), TL=0, TR=1, BL=2, BR=3.
 // Only the first cut[1] digits are computed, the rest of the key is zero: bodies of one cell of
@@ -313,7 +308,7 @@ __global__ __launch_bounds__(256) void k_keys(const double2 *pos, int n, const d
         // a Hilbert curve through the cell: the cells of every level are still contiguous ranges of the
         // sorted bodies, as the tree needs them, and consecutive cells are always neighbours in space
         // (in Z order a quarter of them are not), so the 64 consecutive bodies of a traversal wave
-        // fill a tighter box.  Two tables of 16 two-bit entries, indexed by orientation and quadrant.
+        // fill a tighter box.  Two tables of 16 two-bit entries, indexed by orientation and quadrant (nb_common.h).
         const uint32_t at = 2u * (4u * curve + (((uint32_t)below << 1) | (uint32_t)right));
         k = (k << 2) | (uint64_t)((HILBERT_DIGIT >> at) & 3u);
         curve = (HILBERT_NEXT >> at) & 3u;

@@ -179,38 +179,9 @@ __global__ __launch_bounds__(256) void k_keys3(const double *pos, int n, const d
     }
     // The octants enter the key as their positions along a Hilbert curve (as the quadrants do in
     // k_keys: cells stay contiguous ranges of the sorted bodies, consecutive cells are neighbours
-    // in space, a traversal wave's bodies fill a tighter box).  Skilling's transform of the three
-    // bit strings (Programming the Hilbert curve, AIP Conf. Proc. 707, 2004): a bit of the result
-    // depends on the bits of its own level and above only, so cutting the keys at any level gives the
-    // curve through that level's cells.
-    uint64_t k = 0;
-    if (levels > 0) {
-        const uint32_t top = 1u << (levels - 1);
-        for (uint32_t q = top; q > 1u; q >>= 1) {
-            const uint32_t low = q - 1u;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                if (c[d] & q) {
-                    c[0] ^= low;
-                } else {
-                    const uint32_t t = (c[0] ^ c[d]) & low;
-                    c[0] ^= t;
-                    c[d] ^= t;
-                }
-            }
-        }
-        c[1] ^= c[0];
-        c[2] ^= c[1];
-        uint32_t t = 0u;
-        for (uint32_t q = top; q > 1u; q >>= 1)
-            if (c[2] & q)
-                t ^= q - 1u;
-        c[0] ^= t;
-        c[1] ^= t;
-        c[2] ^= t;
-        for (int l = levels - 1; l >= 0; --l)
-            k = (k << 3) | (uint64_t)((((c[0] >> l) & 1u) << 2) | (((c[1] >> l) & 1u) << 1) | ((c[2] >> l) & 1u));
-    }
+    // in space, a traversal wave's bodies fill a tighter box).  Cut at any level the keys are the
+    // curve through that level's cells (hilbert3_index, nb_common.h).
+    const uint64_t k = hilbert3_index(c[0], c[1], c[2], levels);
     const bool odd = cut[2] & 1u;
     const uint64_t key = levels > 0 ? k << (2 + 3 * (BH3_KEY_LEVELS - levels)) : 0ull;
     if (cut[5] != 0u) {

@@ -13,6 +13,67 @@
 
 namespace nb {
 
+// ---- positions along a Hilbert curve (host and device) ----
+// Bodies are ordered along Hilbert curves -- the tree's keys level by level (nb_bh.hip, nb_bh3.hip) and
+// the slots of the exchange order (nb_handle.h, nb_refresh.hip): the cells of every level are contiguous
+// ranges of the order, as with Z order, and consecutive cells are always neighbours in space (in Z order
+// a quarter of them are not), so runs of consecutive bodies fill tight boxes.
+//
+// 2-D: through the four quadrants of a cell {TL, TR, BL, BR} = {0, 1, 2, 3} (2 * lower half + right
+// half): entry 4 * orientation + quadrant of HILBERT_DIGIT is the quadrant's position along the curve,
+// of HILBERT_NEXT the orientation inside that quadrant (orientation = swap x and y | invert both << 1, 0 at the root).
+constexpr uint32_t HILBERT_DIGIT = 0x1e36b49cu, HILBERT_NEXT = 0xb3da640du;
+
+// Index along the curve of the cell (x, y) of a 2^bits x 2^bits grid (y counted downwards or upwards: either way a Hilbert curve).
+__host__ __device__ inline uint64_t hilbert2_index(uint32_t x, uint32_t y, int bits)
+{
+    uint64_t k = 0;
+    uint32_t curve = 0u;
+    for (int l = bits - 1; l >= 0; --l) {
+        const uint32_t at = 2u * (4u * curve + ((((y >> l) & 1u) << 1) | ((x >> l) & 1u)));
+        k = (k << 2) | (uint64_t)((HILBERT_DIGIT >> at) & 3u);
+        curve = (HILBERT_NEXT >> at) & 3u;
+    }
+    return k;
+}
+
+// 3-D: index along the curve of the cell (c0, c1, c2) of a grid of 2^bits cells per axis, three bits per level,
+// the top level first.  Skilling's transform of the three bit strings (Programming the Hilbert curve, AIP
+// Conf. Proc. 707, 2004): a bit of the result depends on the bits of its own level and above only, so
+// cutting the index at any level gives the curve through that level's cells.
+__host__ __device__ inline uint64_t hilbert3_index(uint32_t c0, uint32_t c1, uint32_t c2, int bits)
+{
+    if (bits <= 0)
+        return 0ull;
+    uint32_t c[3] = {c0, c1, c2};
+    const uint32_t top = 1u << (bits - 1);
+    for (uint32_t q = top; q > 1u; q >>= 1) {
+        const uint32_t low = q - 1u;
+        for (int d = 0; d < 3; ++d) {
+            if (c[d] & q) {
+                c[0] ^= low;
+            } else {
+                const uint32_t t = (c[0] ^ c[d]) & low;
+                c[0] ^= t;
+                c[d] ^= t;
+            }
+        }
+    }
+    c[1] ^= c[0];
+    c[2] ^= c[1];
+    uint32_t t = 0u;
+    for (uint32_t q = top; q > 1u; q >>= 1)
+        if (c[2] & q)
+            t ^= q - 1u;
+    c[0] ^= t;
+    c[1] ^= t;
+    c[2] ^= t;
+    uint64_t k = 0;
+    for (int l = bits - 1; l >= 0; --l)
+        k = (k << 3) | (uint64_t)((((c[0] >> l) & 1u) << 2) | (((c[1] >> l) & 1u) << 1) | ((c[2] >> l) & 1u));
+    return k;
+}
+
 #define NB_HIP(call)                                                                            \
     do {                                                                                        \
         hipError_t nb_e_ = (call);                                                              \

@@ -146,9 +146,9 @@ void choose_units(S *s, const typename S::Body *b, int n)
     s->fc.precise_near = s->fc.cth < 0.05f;
 }
 
-// Exchange order = bodies sorted by a Morton code of their initial positions (2 x 16 bits, every
-// axis scaled to its own range; 3 x 10 bits with one scale for all axes, so that a thin disc is not
-// cut into slabs).  Index ranges of it are compact patches of space, which keeps the 64 bodies a
+// Exchange order = bodies sorted by their position along a Hilbert curve (nb_common.h) through a grid over
+// their initial positions (2 x 16 bits, every axis scaled to its own range; 3 x 10 bits with one scale for
+// all axes, so that a thin disc is not cut into slabs).  Index ranges of it are compact patches of space, which keeps the 64 bodies a
 // wave walks the tree for close together when the range is cut across GPUs, and gives the
 // direct-sum runs small bounding boxes.  Only locality matters here, not the reference's cells.
 template <class S>
@@ -175,27 +175,12 @@ void spatial_order(const typename S::Body *b, int n, std::vector<uint32_t> &orde
         for (int d = 0; d < D; ++d)
             sc[d] = ext > 0 ? 1023.0 / ext : 0.0;
     }
-    auto spread2 = [](uint64_t v) {
-        v = (v | (v << 8)) & 0x00FF00FFull;
-        v = (v | (v << 4)) & 0x0F0F0F0Full;
-        v = (v | (v << 2)) & 0x33333333ull;
-        v = (v | (v << 1)) & 0x55555555ull;
-        return v;
-    };
-    auto spread3 = [](uint64_t v) {
-        v = (v | (v << 16)) & 0x030000FFull;
-        v = (v | (v << 8)) & 0x0300F00Full;
-        v = (v | (v << 4)) & 0x030C30C3ull;
-        v = (v | (v << 2)) & 0x09249249ull;
-        return v;
-    };
     std::vector<uint64_t> kv(n);
     for (int i = 0; i < n; ++i) {
-        uint64_t code = 0;
-        for (int d = 0; d < D; ++d) {
-            const uint64_t q = (uint64_t)(uint32_t)((S::coord(b[i], d) - lo[d]) * sc[d]);
-            code |= (D == 2 ? spread2(q) : spread3(q)) << d;
-        }
+        uint32_t q[3] = {0u, 0u, 0u};
+        for (int d = 0; d < D; ++d)
+            q[d] = (uint32_t)((S::coord(b[i], d) - lo[d]) * sc[d]);
+        const uint64_t code = D == 2 ? hilbert2_index(q[0], q[1], 16) : hilbert3_index(q[0], q[1], q[2], 10);
         kv[i] = (code << 32) | (uint32_t)i;
     }
     std::sort(kv.begin(), kv.end());

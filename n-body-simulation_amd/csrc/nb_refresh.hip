@@ -88,27 +88,9 @@ __global__ __launch_bounds__(256) void k_rf_box(const double *part, int nblk, do
     }
 }
 
-__device__ __forceinline__ uint32_t spread2(uint32_t v)
-{
-    v = (v | (v << 8)) & 0x00FF00FFu;
-    v = (v | (v << 4)) & 0x0F0F0F0Fu;
-    v = (v | (v << 2)) & 0x33333333u;
-    v = (v | (v << 1)) & 0x55555555u;
-    return v;
-}
-
-__device__ __forceinline__ uint64_t spread3(uint64_t v)
-{
-    v = (v | (v << 16)) & 0x030000FFull;
-    v = (v | (v << 8)) & 0x0300F00Full;
-    v = (v | (v << 4)) & 0x030C30C3ull;
-    v = (v | (v << 2)) & 0x09249249ull;
-    return v;
-}
-
-// 2 x 16-bit (2-D; every axis scaled by its own extent) or 3 x 10-bit (3-D; one scale for all axes,
-// so that a thin disc is not cut into slabs) Morton code of every body, in the top 32 bits of the
-// word the radix sort orders.
+// Position of every body along a Hilbert curve through a grid of 2 x 16 bits (2-D; every axis scaled by its
+// own extent) or 3 x 10 bits (3-D; one scale for all axes, so that a thin disc is not cut into slabs), in the
+// top 32 bits of the word the radix sort orders.
 template <int DIMS>
 __global__ __launch_bounds__(256) void k_rf_keys(const double *pos, int n, const double *box, uint64_t *keys, uint32_t *idx)
 {
@@ -120,16 +102,16 @@ __global__ __launch_bounds__(256) void k_rf_keys(const double *pos, int n, const
         const double ex = box[2] - box[0], ey = box[3] - box[1];
         const double sx = ex > 0 ? 65535.0 / ex : 0.0, sy = ey > 0 ? 65535.0 / ey : 0.0;
         const uint32_t qx = (uint32_t)((pos[2 * (size_t)i] - box[0]) * sx), qy = (uint32_t)((pos[2 * (size_t)i + 1] - box[1]) * sy);
-        code = (uint64_t)(spread2(qx) | (spread2(qy) << 1));
+        code = hilbert2_index(qx, qy, 16);
     } else {
         double ext = 0.0;
         for (int d = 0; d < 3; ++d)
             ext = fmax(ext, box[3 + d] - box[d]);
         const double sc = ext > 0 ? 1023.0 / ext : 0.0;
-        code = 0;
+        uint32_t q[3];
         for (int d = 0; d < 3; ++d)
-            code |= spread3((uint64_t)((pos[3 * (size_t)i + d] - box[d]) * sc)) << d;
-        code <<= 2;  // 30 bits, at the top of the 32
+            q[d] = (uint32_t)((pos[3 * (size_t)i + d] - box[d]) * sc);
+        code = hilbert3_index(q[0], q[1], q[2], 10) << 2;  // 30 bits, at the top of the 32
     }
     if (n <= (1 << 30)) {
         keys[i] = (code << 30) | (uint64_t)(uint32_t)i;  // sort_pairs orders key << 2; packed (k_rf_box's cut[5])

@@ -80,7 +80,8 @@ def test_ranks_with_an_empty_slice_step_like_the_others(nb, oracle, dims, alg, n
     # every rank keeps the velocities of its own slots up to date
     for r, o in enumerate(outs):
         own = order[min(n, r * chunk):min(n, (r + 1) * chunk)]
-        assert np.allclose(o["vel"][own], ref["vel"][own], rtol=1e-6, atol=1e-6)
+        # (FP32 sums taken in another order: small components of a velocity differ by 1e-6 of the speed)
+        assert np.allclose(o["vel"][own], ref["vel"][own], rtol=1e-6, atol=1e-6 * np.abs(ref["vel"]).max())
 
 
 def test_partition_is_refused_once_stepped(nb):
