@@ -143,9 +143,9 @@ int nb_set_stream(nb_sim *sim, void *hip_stream);
 
 /* ---- multi-GPU: one process per GPU, every process holds all n bodies ---- */
 
-/* Bodies are held in "exchange order": sorted when they are set by a Morton code of their
- * positions (NB_DBG_ORDER gives the caller index of each slot), so that an index range is a
- * compact patch of space; the order is renewed as described at nb_refresh_order, and a partitioned
+/* Bodies are held in "exchange order": sorted when they are set by their position along a
+ * Hilbert curve (NB_DBG_ORDER gives the caller index of each slot), so that an index range is
+ * a compact patch of space; the order is renewed as described at nb_refresh_order, and a partitioned
  * simulation changes it only there.  This process integrates only the bodies in slots
  * [rank*chunk, min(n,(rank+1)*chunk)), chunk = ceil(n / world).
  * Must be called after the bodies were set and before the first step. */
@@ -224,7 +224,7 @@ int nb_cells_buffer(nb_sim *sim, int which, void **device_ptr, size_t *count_dou
 
 enum nb_debug_array {
     NB_DBG_BBOX = 0,        /* 4 doubles: topLeft.x, topLeft.y, botRight.x, botRight.y */
-    NB_DBG_KEYS = 1,        /* n uint64: Morton key per body, unsorted, exchange order */
+    NB_DBG_KEYS = 1,        /* n uint64: key per body (its quadrant path in the step's box, each digit the quadrant's place along a Hilbert curve), unsorted, exchange order */
     NB_DBG_SORTED_KEYS = 2, /* n uint64 */
     NB_DBG_SORTED_IDX = 3,  /* n uint32: exchange-order index of the k-th sorted body */
     NB_DBG_NODE_RANGE = 4,  /* nnodes x 2 uint32: first sorted body, body count */
@@ -265,7 +265,7 @@ int nb_stage_ms(nb_sim *sim, float *out, int count);
 
 /* Re-derives the exchange order (see NB_DBG_ORDER) from the current positions and re-sorts the
  * device state by it, on the device and asynchronously on the simulation's stream (a bounding box,
- * a radix sort of Morton codes, one gather per per-body array).  Nothing the caller sees changes
+ * a radix sort of positions along a Hilbert curve, one gather per per-body array).  Nothing the caller sees changes
  * (nb_read_bodies keeps returning bodies in the caller's order; results differ only by the
  * rounding of a different summation order); it restores the speed of long runs: the direct-sum
  * kernel relies on neighbouring slots being neighbours in space, and the Barnes-Hut pipeline gathers

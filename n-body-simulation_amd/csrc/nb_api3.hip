@@ -1,6 +1,6 @@
 // nb_api3.hip -- the nb3_ entry points of include/nbody.h: the C ABI of nb_api.hip for
 // three-dimensional bodies.  nb_sim3 owns the device state (FP64 positions, velocities and
-// accelerations as packed triples, in an order sorted once by a Morton code of the initial
+// accelerations as packed triples, in an order sorted by their position along a Hilbert curve through the initial
 // positions) and drives nb_direct3.hip or nb_bh3.hip; bodies are copied back only on request.
 // The entry points themselves are the ones of the 2-D handle (nb_handle.h); this file holds the
 // 3-D pipelines' launches, diagnostics and introspection.

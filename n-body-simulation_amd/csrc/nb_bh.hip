@@ -14,7 +14,7 @@
 //              smallest cell, with the same force.
 //   5 com      bottom-up centre of mass, FP64, children summed in the reference's order
 //              TL,TR,BL,BR (quadtree.cpp:187-228)
-//   6 force    one wave per 64 Morton-consecutive bodies; the wave shares a stack of
+//   6 force    one wave per 64 consecutive bodies of the sorted order; the wave shares a stack of
 //              (sibling group, lane mask) entries in LDS, fetches up to 64 nodes per round trip, and
 //              every lane applies its OWN opening test (barnesHut.cpp:70-71), so each body
 //              accepts exactly the cells the reference accepts for it.  Integration
@@ -490,7 +490,7 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     f.tcount = nullptr;
     int ntarget = a.n;
     if (a.t0 != 0 || a.t1 != a.n) {
-        // this rank integrates only bodies [t0, t1): walk them in Morton order
+        // this rank integrates only bodies [t0, t1): walk them in the sorted order
         NB_TRY(bh_target_list(s, b.idx[b.sorted], a.n, a.t0, a.t1, b.tblock, b.tlist, b.tcount));
         f.tlist = b.tlist;
         f.tcount = b.tcount;

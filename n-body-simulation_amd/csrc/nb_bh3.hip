@@ -9,7 +9,7 @@
 //   3 sort   the radix sort of nb_bh.hip
 //   4 build  the level-by-level build of nb_bh.hip with 3-bit digits (up to 8 children)
 //   5 com    bottom-up centres of mass, children summed in digit order
-//   6 force  one wave per 64 Morton-consecutive bodies with a shared stack in LDS, every lane
+//   6 force  one wave per 64 consecutive bodies of the sorted order with a shared stack in LDS, every lane
 //            applying its own opening test, fused integration
 // As in 2-D, cells that no body can ever open (width / theta + diagonal < collision_th) are not
 // built below: the keys stop at that level and its cells become leaves holding several bodies.
@@ -572,7 +572,7 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     f.tcount = nullptr;
     int ntarget = a.n;
     if (a.t0 != 0 || a.t1 != a.n) {
-        // this rank integrates only bodies [t0, t1): walk them in Morton order
+        // this rank integrates only bodies [t0, t1): walk them in the sorted order
         NB_TRY(bh_target_list(s, b.idx[0], a.n, a.t0, a.t1, b.tblock, b.tlist, b.tcount));
         f.tlist = b.tlist;
         f.tcount = b.tcount;

@@ -1,5 +1,5 @@
-// nb_bh_sort.hip -- the radix sort of the Barnes-Hut pipeline (2-D and 3-D keys, and the Morton
-// codes of the order renewal) and the compaction that lists a rank's targets.  The reference sorts
+// nb_bh_sort.hip -- the radix sort of the Barnes-Hut pipeline (2-D and 3-D keys, and the curve
+// indices of the order renewal) and the compaction that lists a rank's targets.  The reference sorts
 // nothing: its GPU program regroups the bodies level by level with atomics
 // (src/gpu/BH/barnesHut_kernel.cu:245-288), its CPU program inserts them one by one
 // (src/cpu/quadtree.cpp:73-144).

@@ -16,7 +16,7 @@
 //
 // The reference's near-field cutoff (pairs closer than r_i + r_j + collision_th are skipped,
 // directSum.cpp:69-72) costs a third of the pair arithmetic, yet only concerns bodies within
-// ~1 % of the domain of each other.  Bodies are held in Morton order, so a wave's targets and a
+// ~1 % of the domain of each other.  Bodies are held in the order of a Hilbert curve, so a wave's targets and a
 // run of T::SUB consecutive sources occupy small boxes; when the two boxes are farther apart than
 // the largest possible cutoff, the run is processed by a loop without the test.  Runs whose bodies
 // all have one mass (the planets of every reference scenario) also skip the per-pair multiply by

@@ -1,9 +1,9 @@
 // nb_refresh.h -- re-deriving the exchange order on the device (internal).
 //
-// Bodies are held sorted by a Morton code of their positions when they were set; they wander, and
+// Bodies are held sorted by their position along a Hilbert curve (nb_common.h) when they were set; they wander, and
 // the direct-sum kernel (whose run-against-wave box tests rely on neighbouring slots being
 // neighbours in space) slows down as they do.  The reference keeps bodies in creation order and
-// has nothing of the kind.  The renewal is a bounding box, a radix sort of (Morton code, slot)
+// has nothing of the kind.  The renewal is a bounding box, a radix sort of (curve index, slot)
 // pairs and one gather per per-body array, all enqueued on the simulation's stream: the host does
 // not wait, and a partitioned run can do it too (every rank holds all positions, so every rank
 // derives the same order).

@@ -115,7 +115,7 @@ struct TraversalSizes {
     static_assert(T::ENTRIES >= 1 && T::GROUP * T::ENTRIES <= 64, "one group of lanes per popped entry");
 };
 
-// One wave per 64 Morton-consecutive targets, eight waves per SIMD.
+// One wave per 64 consecutive targets of the sorted order, eight waves per SIMD.
 template <int DIM, int MODE, bool STATS>
 __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<DIM>::Args &a)
 {
