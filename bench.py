@@ -515,21 +515,26 @@ def main():
         got = profiled.get(counters_of) or {}
         if "slots_per_vector_instruction" not in census or "valu_wave_insts" not in got or not kernel_ms:
             return None
-        slots = (got["valu_wave_insts"] * census["slots_per_vector_instruction"]
-                 + got.get("lds_wave_insts", 0.0) * census["slots_per_lds_instruction"])
+        # every LDS instruction takes one issue slot of its SIMD; what it costs beyond that (the LDS pipe's
+        # own time) overlaps with the other waves' vector work to a degree that depends on the state
+        vslots = got["valu_wave_insts"] * census["slots_per_vector_instruction"]
+        lds = got.get("lds_wave_insts", 0.0)
+        slots = vslots + lds
+        peak = census["issue_rate_wave_slots_per_s"]
         rate = slots / (kernel_ms * 1e-3)
+        marginal = (vslots + lds * census["slots_per_lds_instruction"]) / (kernel_ms * 1e-3)
         return {"bound": "vector issue", "unit": "wave-instruction slots/s", "achieved": rate,
-                "peak": census["issue_rate_wave_slots_per_s"], "frac": rate / census["issue_rate_wave_slots_per_s"],
+                "peak": peak, "frac": rate / peak,
                 "slots_per_launch": slots, "valu_wave_insts": got["valu_wave_insts"],
                 "salu_wave_insts": got.get("salu_wave_insts"), "lds_wave_insts": got.get("lds_wave_insts"),
                 "slots_per_vector_instruction": census["slots_per_vector_instruction"],
-                "slots_per_lds_instruction": census["slots_per_lds_instruction"],
+                "lds_at_marginal_cost": {"slots_per_lds_instruction": census["slots_per_lds_instruction"], "frac": marginal / peak,
+                                         "note": "an LDS read priced at what adding one per visit cost the early state "
+                                                 "(bin/microbench: 3.3 vector slots): 0.96 there, above 1 in the late state, "
+                                                 "where that price evidently does not hold -- the true figure lies between the two"},
                 "source": "SQ_INSTS_VALU / SQ_INSTS_LDS per launch from the rocprofv3 --pmc pass recorded in profiles/traffic.json "
-                          "(%s); slot weights and the issue rate (v_fma_f32: 58 T lane-ops/s) measured by bin/microbench; "
-                          "not counters of this run" % got.get("workload", ""),
-                "accuracy": "the slot prices are single numbers fitted to microbenchmarks (an LDS read 3.3 vector slots, "
-                            "whatever else the SIMD issues beside it): good to about 5 %, so a launch that stalls on "
-                            "nothing can read slightly above 1"}
+                          "(%s); the vector instructions' slot weights (static mix of the hot loop) and the issue rate "
+                          "(v_fma_f32: 58 T lane-ops/s) measured by bin/microbench; not counters of this run" % got.get("workload", "")}
     roofline = {"bound": "hbm", "kernel": "k_bh_force", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "l2_hit_rate": l2_hit, "kernel_ms": force_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
