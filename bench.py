@@ -54,6 +54,22 @@ def load_package():
     return mod
 
 
+PREWARM_S = 0.1
+
+
+def prewarm(sim):
+    """Brings the GPU's clocks to their steady state before a measurement: force evaluations of the
+    simulation's own state (nb_compute_accel: nothing is advanced, the steps that follow are the same steps)
+    for PREWARM_S seconds.  Setting the bodies leaves the GPU idle for a second or more while the host orders
+    them; the first thirty steps after that run 5-15 % slower than the thirtieth (tools/clock_ramp_probe.py),
+    and K timed steps after W warm-up steps would measure that transient instead of the step."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < PREWARM_S:
+        for _ in range(4):
+            sim.evaluate()
+        sim.sync()
+
+
 def barrier_sync(world):
     torch.cuda.synchronize()
     if world > 1:
@@ -62,7 +78,7 @@ def barrier_sync(world):
 
 
 def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=True, params=None, late_at=0,
-              cells=False):
+              cells=False, warm_clocks=True):
     """Returns (seconds for `steps` steps, max over ranks; mean per-stage ms of this rank; traversal
     counters of rank 0; and, with late_at > 0 (one step number or several), the same timing repeated
     once the run has reached that step: {"ms_per_step", "stage_ms", "at_step"}, further steps as a
@@ -118,18 +134,32 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
             step = lambda: stepper.update(1)  # noqa: E731
     else:
         step = lambda: sim.update(1)  # noqa: E731
+    if world == 1 and warm_clocks:
+        prewarm(sim)
     for _ in range(warmup):
         step()
-    sim.set_stage_timing(stage_timing, counters=False)
-    stages = {}
-    barrier_sync(world)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    barrier_sync(world)
-    dt = time.perf_counter() - t0
-    if stage_timing:
-        stages = sim.stage_ms()  # HIP events recorded over these steps, read only now: mean per step
+
+    def timed_block():
+        # the K timed steps run without the stage timer (its seven event records per step cost about 1 % of a
+        # 1 ms step); the per-stage times come from K further steps with the timer on
+        sim.set_stage_timing(False, counters=False)
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier_sync(world)
+        took = time.perf_counter() - t0
+        per_stage = {}
+        if stage_timing:
+            sim.set_stage_timing(True, counters=False)
+            for _ in range(steps):
+                step()
+            barrier_sync(world)
+            per_stage = sim.stage_ms()  # HIP events recorded over these steps, read only now: mean per step
+            sim.set_stage_timing(False, counters=False)
+        return took, per_stage, steps * (2 if stage_timing else 1)
+
+    dt, stages, ran = timed_block()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -146,26 +176,19 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
     elif alg == nb.BARNES_HUT and world > 1:
         step()  # keep the ranks' collectives matched with rank 0's extra step
     late = None
-    done = warmup + steps + (1 if alg == nb.BARNES_HUT else 0)
+    done = warmup + ran + (1 if alg == nb.BARNES_HUT else 0)
     for at in sorted(a for a in (late_at if isinstance(late_at, (tuple, list)) else (late_at,)) if a > 0):
         if at <= done:
             continue
         sim.set_stage_timing(False, counters=False)
         for _ in range(at - done):
             step()
-        sim.set_stage_timing(stage_timing, counters=False)
-        barrier_sync(world)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        barrier_sync(world)
-        ldt = time.perf_counter() - t0
-        lstages = sim.stage_ms() if stage_timing else {}
+        ldt, lstages, lran = timed_block()
         if world > 1:
             t = torch.tensor([ldt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ldt = float(t.item())
-        done = at + steps
+        done = at + lran
         entry = {"at_step": at, "ms_per_step": ldt * 1e3 / steps, "stage_ms": lstages}
         if late is None:
             late = entry
@@ -184,14 +207,17 @@ def three_d_leg(nb, bh_n, direct_n, steps, warmup):
     b = nb.init_scenario3(nb.COLLISION, bh_n, 12345, 2.0e10)
     with nb.NBodySim3(bh_n, nb.BARNES_HUT) as sim:
         sim.set_bodies(b)
+        prewarm(sim)
         sim.update(warmup)
-        sim.set_stage_timing(True, counters=False)
         torch.cuda.synchronize()
         sim.sync()
         t0 = time.perf_counter()
         sim.update(steps)
         sim.sync()
         dt = time.perf_counter() - t0
+        sim.set_stage_timing(True, counters=False)  # (the stage times: from further steps, as in timed_run)
+        sim.update(steps)
+        sim.sync()
         stages = sim.stage_ms()
         sim.set_stage_timing(False, counters=True)
         sim.update(1)
@@ -203,6 +229,7 @@ def three_d_leg(nb, bh_n, direct_n, steps, warmup):
     b = nb.init_scenario3(nb.SPIRAL, direct_n, 12345, 2.0e10)
     with nb.NBodySim3(direct_n, nb.DIRECT) as sim:
         sim.set_bodies(b)
+        prewarm(sim)
         sim.update(1)
         sim.sync()
         t0 = time.perf_counter()
@@ -426,6 +453,15 @@ def main():
                                            late_at=(args.late_step, args.later_step if args.late_step > 0 else 0),
                                            cells=cells)
     ms_per_step = dt * 1e3 / args.steps
+    # the same K steps after the same W warm-up steps without warming the clocks first: what a run's first
+    # steps take right after the bodies were uploaded
+    cold = None
+    if world == 1 and not args.headline_only:
+        cdt, _, _, _ = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device, stage_timing=False,
+                                 warm_clocks=False)
+        cold = {"ms_per_step": cdt * 1e3 / args.steps,
+                "note": "steps W+1..W+K of a fresh handle without clock_prewarm: the GPU's clocks are still in the transient "
+                        "that follows the idle upload of the bodies (tools/clock_ramp_probe.py)"}
     gathered = None
     if cells:
         pdt, pstages, _, _ = timed_run(nb, nb.BARNES_HUT, bodies, args.steps, args.warmup, rank, world, device)
@@ -595,6 +631,11 @@ def main():
         },
         "speedup_vs_published": PUBLISHED_MS / ms_per_step,
         "stage_ms": stages,
+        "cold_start": cold,
+        "clock_prewarm": "one GPU: %.1f s of force evaluations of the unchanged initial state (nb_compute_accel) before the W warm-up steps, "
+                         "so that the K timed steps run at the clocks a run settles to and not in the transient after the idle upload" % PREWARM_S,
+        "stage_ms_note": "HIP-event times of the K steps that follow the K timed ones: the timed steps run without the stage "
+                         "timer, whose event records cost about 1 % of a step",
         "tree": counters,
         "late_state": late,
         "position_exchange": gathered,

@@ -234,6 +234,11 @@ class NBodySim:
         b = np.ascontiguousarray(bodies, dtype=BODY_DTYPE)
         _check(self._lib.nb_set_bodies(self._h, b.ctypes.data_as(C.c_void_p), len(b)))
 
+    def evaluate(self):
+        """Enqueues one force evaluation (nb_compute_accel) and returns at once: the state is left as it is,
+        the stored accelerations are those of the current positions."""
+        _check(self._lib.nb_compute_accel(self._h))
+
     def compute_accel(self):
         _check(self._lib.nb_compute_accel(self._h))
         return self.read_bodies()["acc"]
@@ -413,6 +418,10 @@ class NBodySim3:
     def set_bodies(self, bodies):
         b = np.ascontiguousarray(bodies, dtype=BODY3_DTYPE)
         _check(self._lib.nb3_set_bodies(self._h, b.ctypes.data_as(C.c_void_p), len(b)))
+
+    def evaluate(self):
+        """Enqueues one force evaluation (nb3_compute_accel) and returns at once (see NBodySim.evaluate)."""
+        _check(self._lib.nb3_compute_accel(self._h))
 
     def compute_accel(self):
         _check(self._lib.nb3_compute_accel(self._h))
