@@ -556,7 +556,11 @@ def main():
         vslots = got["valu_wave_insts"] * census["slots_per_vector_instruction"]
         lds = got.get("lds_wave_insts", 0.0)
         slots = vslots + lds
-        peak = census["issue_rate_wave_slots_per_s"]
+        # peak: a SIMD issues one wave64 vector instruction every two cycles (32 lanes a cycle: 157.3 TFLOP/s of FMA at
+        # 2.4 GHz): 256 CUs x 4 SIMDs x 2.4e9 / 2.  The clock under this load cannot be read here; an FMA-only kernel
+        # sustains 62 T lane-ops/s (bin/microbench, 8 waves per SIMD), 79 % of that rate, power-limited.
+        peak = 256 * 4 * 2.4e9 / 2
+        fma_rate = census["issue_rate_wave_slots_per_s"]
         rate = slots / (kernel_ms * 1e-3)
         marginal = (vslots + lds * census["slots_per_lds_instruction"]) / (kernel_ms * 1e-3)
         return {"bound": "vector issue", "unit": "wave-instruction slots/s", "achieved": rate,
@@ -564,13 +568,15 @@ def main():
                 "slots_per_launch": slots, "valu_wave_insts": got["valu_wave_insts"],
                 "salu_wave_insts": got.get("salu_wave_insts"), "lds_wave_insts": got.get("lds_wave_insts"),
                 "slots_per_vector_instruction": census["slots_per_vector_instruction"],
+                "against_sustained_fma_rate": {"rate": fma_rate, "frac": rate / fma_rate,
+                                               "note": "the rate an FMA-only kernel sustains (power-limited clock); this kernel "
+                                                       "draws less and may clock higher, so this figure can pass 1"},
                 "lds_at_marginal_cost": {"slots_per_lds_instruction": census["slots_per_lds_instruction"], "frac": marginal / peak,
-                                         "note": "an LDS read priced at what adding one per visit cost the early state "
-                                                 "(bin/microbench: 3.3 vector slots): 0.96 there, above 1 in the late state, "
-                                                 "where that price evidently does not hold -- the true figure lies between the two"},
+                                         "note": "an LDS read priced at what adding one per visit cost (3.3 vector slots in the "
+                                                 "first steps after an upload) instead of its one issue slot: an upper estimate"},
                 "source": "SQ_INSTS_VALU / SQ_INSTS_LDS per launch from the rocprofv3 --pmc pass recorded in profiles/traffic.json "
-                          "(%s); the vector instructions' slot weights (static mix of the hot loop) and the issue rate "
-                          "(v_fma_f32: 58 T lane-ops/s) measured by bin/microbench; not counters of this run" % got.get("workload", "")}
+                          "(%s); the vector instructions' slot weights (static mix of the hot loop) from profiles/issue_census.py; "
+                          "not counters of this run" % got.get("workload", "")}
     roofline = {"bound": "hbm", "kernel": "k_bh_force", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "l2_hit_rate": l2_hit, "kernel_ms": force_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "_ZN2nb10k_bh_forceILi0ELb0EEEvNS_9ForceArgsE"
 WEIGHTS = {"plain": 1.0, "packed": 2.0, "transcendental": 2.0, "mask": 1.6}
 LDS_SLOTS = 3.3
-ISSUE_RATE = 58.0e12 / 64.0  # wave-instruction slots per second: 58 T lane-ops/s of v_fma_f32 (bin/microbench)
+ISSUE_RATE = 62.0e12 / 64.0  # wave-instruction slots per second an FMA-only kernel sustains: 62 T lane-ops/s of v_fma_f32 (bin/microbench, 8 waves per SIMD)
 
 
 def census():
