@@ -134,7 +134,7 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
             step = lambda: stepper.update(1)  # noqa: E731
     else:
         step = lambda: sim.update(1)  # noqa: E731
-    if world == 1 and warm_clocks:
+    if world == 1 and warm_clocks and PREWARM_S > 0:
         prewarm(sim)
     for _ in range(warmup):
         step()
@@ -207,7 +207,8 @@ def three_d_leg(nb, bh_n, direct_n, steps, warmup):
     b = nb.init_scenario3(nb.COLLISION, bh_n, 12345, 2.0e10)
     with nb.NBodySim3(bh_n, nb.BARNES_HUT) as sim:
         sim.set_bodies(b)
-        prewarm(sim)
+        if PREWARM_S > 0:
+            prewarm(sim)
         sim.update(warmup)
         torch.cuda.synchronize()
         sim.sync()
@@ -229,7 +230,8 @@ def three_d_leg(nb, bh_n, direct_n, steps, warmup):
     b = nb.init_scenario3(nb.SPIRAL, direct_n, 12345, 2.0e10)
     with nb.NBodySim3(direct_n, nb.DIRECT) as sim:
         sim.set_bodies(b)
-        prewarm(sim)
+        if PREWARM_S > 0:
+            prewarm(sim)
         sim.update(1)
         sim.sync()
         t0 = time.perf_counter()
@@ -395,6 +397,9 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline run (and its late states): no GPU-tree mode, N = 50M, direct sum, 3-D, CPU or "
                          "projection legs -- what the counter passes of profiles/collect.sh run")
+    ap.add_argument("--no-prewarm", action="store_true",
+                    help="do not warm the clocks before the warm-up steps (the counter passes of profiles/collect.sh: "
+                         "their first launches of the traversal are then the first steps)")
     ap.add_argument("--no-projection", action="store_true",
                     help="one GPU: skip the per-rank kernel times of a run cut over 2/4/8 ranks (projected_scaling)")
     ap.add_argument("--position-exchange", action="store_true",
@@ -404,6 +409,9 @@ def main():
                     help="and once more from this step on (ejected bodies have stretched the box: the tree closes at level 11); "
                          "0 or --late-step 0: no")
     args = ap.parse_args()
+    if args.no_prewarm:
+        global PREWARM_S
+        PREWARM_S = 0.0
     if args.headline_only:
         args.no_cpu = args.no_direct = args.no_50m = args.no_projection = True
 
@@ -638,7 +646,7 @@ def main():
         "speedup_vs_published": PUBLISHED_MS / ms_per_step,
         "stage_ms": stages,
         "cold_start": cold,
-        "clock_prewarm": "one GPU: %.1f s of force evaluations of the unchanged initial state (nb_compute_accel) before the W warm-up steps, "
+        "clock_prewarm": None if PREWARM_S <= 0 or world > 1 else "one GPU: %.1f s of force evaluations of the unchanged initial state (nb_compute_accel) before the W warm-up steps, "
                          "so that the K timed steps run at the clocks a run settles to and not in the transient after the idle upload" % PREWARM_S,
         "stage_ms_note": "HIP-event times of the K steps that follow the K timed ones: the timed steps run without the stage "
                          "timer, whose event records cost about 1 % of a step",

@@ -17,6 +17,6 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VAL
   TAG=$(echo $C | tr ' ' '_' | cut -c1-40)
   # the headline run alone, early (steps 2-3) and late (steps 300-301): summarize.py takes the first
   # three and the last two launches of the traversal kernel apart
-  timeout -s KILL 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$TAG -- python3 bench.py --steps 2 --warmup 1 --headline-only --late-step 300 --later-step 0 > $OUT/pmc_$TAG.json 2> $OUT/pmc_$TAG.err || exit 1
+  timeout -s KILL 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$TAG -- python3 bench.py --steps 2 --warmup 1 --headline-only --no-prewarm --late-step 300 --later-step 0 > $OUT/pmc_$TAG.json 2> $OUT/pmc_$TAG.err || exit 1
 done
 echo collected

@@ -98,7 +98,7 @@ def main():
                 "fetch_bytes_doubled": 2 * fetch,
                 "write_bytes": write,
                 "l2_hit_rate": summary[k].get("l2_hit_rate"),
-                "workload": "galaxy collision N=5,000,000, %s (bench.py --steps 2 --warmup 1 --headline-only "
+                "workload": "galaxy collision N=5,000,000, %s (bench.py --steps 2 --warmup 1 --headline-only --no-prewarm "
                             "--late-step 300 --later-step 0)" % what,
                 "round": rnd,
             }
