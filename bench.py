@@ -70,6 +70,24 @@ def prewarm(sim):
         sim.sync()
 
 
+_SPARE = {}
+
+
+def prewarm_beside(nb):
+    """The same for a rank of a multi-GPU run, whose simulation cannot evaluate forces by itself (with the
+    cell exchange it does not hold the other ranks' positions, and a loop bounded by time would issue a
+    different number of collectives on every rank): PREWARM_S seconds of steps of a small direct-sum
+    system of this rank's own, which touches neither the simulation nor the communicator."""
+    if "sim" not in _SPARE:
+        _SPARE["sim"] = nb.NBodySim(65536, nb.DIRECT)
+        _SPARE["sim"].set_bodies(nb.init_scenario(nb.SPIRAL, 65536, 1))
+    spare = _SPARE["sim"]
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < PREWARM_S:
+        spare.update(8)
+        spare.sync()
+
+
 def barrier_sync(world):
     torch.cuda.synchronize()
     if world > 1:
@@ -134,8 +152,11 @@ def timed_run(nb, alg, bodies, steps, warmup, rank, world, device, stage_timing=
             step = lambda: stepper.update(1)  # noqa: E731
     else:
         step = lambda: sim.update(1)  # noqa: E731
-    if world == 1 and warm_clocks and PREWARM_S > 0:
-        prewarm(sim)
+    if warm_clocks and PREWARM_S > 0:
+        if world == 1:
+            prewarm(sim)
+        else:
+            prewarm_beside(nb)
     for _ in range(warmup):
         step()
 
@@ -528,6 +549,8 @@ def main():
                 proj.update({k: v for k, v in projected_scaling(
                     nb, [("direct_sum_n%d" % n, nb.DIRECT, b, ddt * 1e3 / steps, (2, 4, 8))]).items() if k != "note"})
 
+    if "sim" in _SPARE:
+        _SPARE.pop("sim").close()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -646,8 +669,12 @@ def main():
         "speedup_vs_published": PUBLISHED_MS / ms_per_step,
         "stage_ms": stages,
         "cold_start": cold,
-        "clock_prewarm": None if PREWARM_S <= 0 or world > 1 else "one GPU: %.1f s of force evaluations of the unchanged initial state (nb_compute_accel) before the W warm-up steps, "
-                         "so that the K timed steps run at the clocks a run settles to and not in the transient after the idle upload" % PREWARM_S,
+        "clock_prewarm": None if PREWARM_S <= 0 else (
+            ("one GPU: %.1f s of force evaluations of the unchanged initial state (nb_compute_accel)" if world == 1 else
+             "every rank: %.1f s of steps of a 65,536-body direct-sum system of its own (the simulation and its communicator "
+             "are not touched)") % PREWARM_S +
+            " before the W warm-up steps, so that the K timed steps run at the clocks a run settles to and not in the "
+            "transient after the idle upload"),
         "stage_ms_note": "HIP-event times of the K steps that follow the K timed ones: the timed steps run without the stage "
                          "timer, whose event records cost about 1 % of a step",
         "tree": counters,
