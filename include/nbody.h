@@ -244,6 +244,8 @@ enum nb_debug_array {
                                lane, visited for all of them (force only), [3] the same under a lane mask,
                                [4] per-lane opening test only (far from every cutoff), [5] all per-lane tests,
                                [6] bodies, [7] per-lane cutoff test only (acceptance settled for the group) */
+    NB_DBG_WAVE_COST = 12,  /* ceil(targets / 64) uint32: what the wave of each group of 64 consecutive targets of the last
+                             * traversal took, in ticks of 10 ns */
     NB_DBG_KEY_LEVELS = 10  /* 2 uint32: [0] the first tree level whose cells no body can open (wider cutoff
                                than opening distance; 32 = none), [1] the number of levels the keys hold:
                                bodies that share a cell of that level share a leaf */

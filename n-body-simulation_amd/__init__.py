@@ -53,6 +53,7 @@ DBG_BBOX, DBG_KEYS, DBG_SORTED_KEYS, DBG_SORTED_IDX = 0, 1, 2, 3
 DBG_NODE_RANGE, DBG_NODE_CHILD, DBG_NODE_COM, DBG_LEVEL_START, DBG_ORDER, DBG_COUNTERS = 4, 5, 6, 7, 8, 9
 DBG_KEY_LEVELS = 10
 DBG_VISIT_KINDS = 11
+DBG_WAVE_COST = 12
 
 STATIC_MAX_BODIES = 131072  # NB_STATIC_MAX_BODIES of include/nbody.h
 

@@ -690,6 +690,10 @@ int nb_debug_read(nb_sim *s, int which, void *out, size_t bytes, size_t *written
         src = s->bh.counters;
         need = sizeof(unsigned long long) * 8;
         break;
+    case NB_DBG_WAVE_COST:
+        src = s->bh.wave_cost;
+        need = sizeof(uint32_t) * (((size_t)(s->t1 - s->t0) + 63) / 64);
+        break;
     case NB_DBG_VISIT_KINDS:
         src = s->bh.counters + 8;
         need = sizeof(unsigned long long) * 8;

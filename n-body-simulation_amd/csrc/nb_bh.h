@@ -49,9 +49,10 @@ struct BhBuffers {
     uint2 *node_child = nullptr;  // x = first child slot << 4 | mask of the child slots in use, y = float
                                   // bits of the prune threshold: (collision_th - cell diagonal)^2, or -1
     uint32_t *tlist = nullptr;    // sorted positions of this rank's targets (multi-GPU), else unused
-    uint32_t *tcount = nullptr;   // 1 entry: number of targets in tlist
+    uint32_t *tcount = nullptr;   // 1 entry: number of entries in tlist (groups of 64, see bh_target_list)
     uint32_t *tblock = nullptr;   // per-block target counts (scratch of the compaction)
     unsigned long long *counters = nullptr;  // 16 statistics words (NB_DBG_COUNTERS, NB_DBG_VISIT_KINDS)
+    uint32_t *wave_cost = nullptr;           // what each 64-body group of the last traversal took, in 10 ns ticks (NB_DBG_WAVE_COST)
     uint32_t *levels_host = nullptr;  // pinned host word: tree levels of the last finished step
     uint32_t *hint_host = nullptr;    // pinned host word: level of the leaves of the last finished step's tree
     double *hint_box = nullptr;       // pinned host: width and height of the last finished step's bounding box
@@ -137,9 +138,14 @@ int launched_levels(const uint32_t *levels_host);
 // When the tree is complete: counters[2] = nodes, [3] = levels; *levels_host = levels (pinned host word).
 int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node_meta, void *split, uint32_t *level_start,
                uint32_t *bsum, unsigned long long *counters, int launched, uint32_t *levels_host);
-// Sorted positions k whose body sorted_idx[k] lies in [t0, t1), ascending, into tlist (n words);
-// their number into *tcount; tblock: target_list_blocks(n) words of scratch.
+// Sorted positions k whose body sorted_idx[k] lies in [t0, t1), ascending, into tlist (target_list_capacity(n)
+// words) in groups of 64 entries: the targets of every tile of the sorted order start a group of their own, and
+// the entries a tile's last group has left over are TL_PAD.  The number of entries, a multiple of 64, into
+// *tcount (at most 64 target_list_groups(n, t1 - t0)); tblock: target_list_blocks(n) words of scratch.
+constexpr uint32_t TL_PAD = 0xffffffffu;
 size_t target_list_blocks(int n);
+size_t target_list_capacity(int n);
+int target_list_groups(int n, int ntarget);
 int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int t1, uint32_t *tblock, uint32_t *tlist,
                    uint32_t *tcount);
 // Second half of the leaf pass: adds to every run of equal keys that crosses 64-body chunk

@@ -380,6 +380,7 @@ struct ForceArgs {
     double2 *pos_w, *vel_w, *acc_w;
     BodyArrays2 from, to;
     unsigned long long *counters;
+    uint32_t *wave_cost;  // may be null: per group of 64 targets, the time its wave took (10 ns ticks)
     int n;
     ForceConsts fc;
     IntegrateArgs ia;
@@ -508,10 +509,11 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     f.vel_w = f.to.pos ? f.to.vel : f.vel;
     f.acc_w = f.to.pos ? f.to.acc : f.acc;
     f.counters = b.counters;
+    f.wave_cost = b.wave_cost;
     f.n = a.n;
     f.fc = a.fc;
     f.ia = a.ia;
-    const int waves = (ntarget + 63) / 64;
+    const int waves = f.tlist ? target_list_groups(a.n, ntarget) : (ntarget + 63) / 64;
     dim3 grid((waves + TR_WPB - 1) / TR_WPB);
     if (ntarget <= 0)
         return NB_OK;
@@ -566,10 +568,11 @@ static int bh_layout(BhBuffers &b, int n, bool with_pyramid, Alloc &&alloc)
     NB_TRY(alloc(b.node_com, 4 * b.node_cap));
     NB_TRY(alloc(b.node_rec, b.node_cap));
     NB_TRY(alloc(b.node_child, b.node_cap));
-    NB_TRY(alloc(b.tlist, (size_t)n));
+    NB_TRY(alloc(b.tlist, target_list_capacity(n)));
     NB_TRY(alloc(b.tcount, 4));
     NB_TRY(alloc(b.tblock, target_list_blocks(n)));
     NB_TRY(alloc(b.counters, 16));
+    NB_TRY(alloc(b.wave_cost, (size_t)target_list_groups(n, n) + 2));
     if (with_pyramid) {
         // first / one-past-last sorted body of every cell of the deepest pyramid level
         NB_TRY(alloc(b.pc_range, (size_t)1 << (2 * b.pyr_max)));
@@ -648,6 +651,7 @@ void bh_free(BhBuffers &b)
         (void)hipFree(b.tcount);
         (void)hipFree(b.tblock);
         (void)hipFree(b.counters);
+        (void)hipFree(b.wave_cost);
         (void)hipFree(b.pc_range);
         (void)hipFree(b.agg);
         (void)hipFree(b.red4);

@@ -489,6 +489,7 @@ struct Force3Args {
     const double *radius;
     double *pos, *vel, *acc;  // packed triples
     unsigned long long *counters;
+    uint32_t *wave_cost;
     int n;
     ForceConsts fc;
     IntegrateArgs ia;
@@ -586,12 +587,13 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     f.vel = a.vel;
     f.acc = a.acc;
     f.counters = b.counters;
+    f.wave_cost = nullptr;
     f.n = a.n;
     f.fc = a.fc;
     f.ia = a.ia;
     f.theta = a.theta;
     f.collision_th = a.collision_th;
-    const int waves = (ntarget + 63) / 64;
+    const int waves = f.tlist ? target_list_groups(a.n, ntarget) : (ntarget + 63) / 64;
     const dim3 grid((waves + TR3_WPB - 1) / TR3_WPB);
     const int mode = a.fc.exact_denom ? FM_EXACT : (a.fc.eps2_negligible ? FM_NOEPS : FM_EPS);
     if (a.collect_stats) {
@@ -643,7 +645,7 @@ int bh3_alloc(Bh3Buffers &b, int n)
     NB_TRY(dev_alloc(b.node_com, 6 * b.node_cap));
     NB_TRY(dev_alloc(b.node_rec, b.node_cap));
     NB_TRY(dev_alloc(b.node_aux, b.node_cap));
-    NB_TRY(dev_alloc(b.tlist, (size_t)n));
+    NB_TRY(dev_alloc(b.tlist, target_list_capacity(n)));
     NB_TRY(dev_alloc(b.tcount, 4));
     NB_TRY(dev_alloc(b.tblock, target_list_blocks(n)));
     NB_TRY(dev_alloc(b.counters, 16));

@@ -354,6 +354,13 @@ int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 }
 
 // ---- targets of this rank (multi-GPU): sorted positions k whose body lies in [t0, t1) ----
+// The list is cut into the traversal's groups of 64 entries, and every tile of TL_TILE sorted positions starts a
+// group of its own (the entries left over in a tile's last group are TL_PAD): a group's targets then lie within
+// one tile of the sorted order.  A rank's slots are a piece of the curve the bodies were ordered along when the
+// slots were dealt, so nearly all of its targets are one run of the sorted order -- but the few that have crossed
+// one of the curve's jumps since sit anywhere, and 64 of those in one group made a wave whose box was the whole
+// system: it walked the tree for every lane by itself and the launch waited for it (236 of 240 us for a
+// sixteenth of 5 M bodies).  One group per stray body costs a wave slot for the time of an ordinary wave.
 
 constexpr int TL_ITEMS = 8;
 constexpr int TL_TILE = 256 * TL_ITEMS;
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(256) void k_tl_count(const uint32_t *idx, int n, ui
     }
     const int tot = block_sum_256(c);
     if (threadIdx.x == 0)
-        bcount[blockIdx.x] = (uint32_t)tot;
+        bcount[blockIdx.x] = (uint32_t)((tot + 63) & ~63);
 }
 
 __global__ __launch_bounds__(256) void k_tl_emit(const uint32_t *idx, int n, uint32_t t0, uint32_t t1,
@@ -392,16 +399,22 @@ __global__ __launch_bounds__(256) void k_tl_emit(const uint32_t *idx, int n, uin
         c += own[it] ? 1 : 0;
     }
     int tot;
-    int pos = (int)bcount_excl[blockIdx.x] + block_excl_scan_256(c, tot);
+    const int first = (int)bcount_excl[blockIdx.x];
+    int pos = first + block_excl_scan_256(c, tot);
 #pragma unroll
     for (int it = 0; it < TL_ITEMS; ++it)
         if (own[it])
             tlist[pos++] = (uint32_t)(base + it);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255)
-        *tcount = (uint32_t)pos;
+    const int padded = (tot + 63) & ~63;
+    if ((int)threadIdx.x < padded - tot)  // at most 63 entries
+        tlist[first + tot + (int)threadIdx.x] = TL_PAD;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        *tcount = (uint32_t)(first + padded);
 }
 
 size_t target_list_blocks(int n) { return (size_t)(n + TL_TILE - 1) / TL_TILE + 1; }
+size_t target_list_capacity(int n) { return (size_t)n + 64 * target_list_blocks(n); }
+int target_list_groups(int n, int ntarget) { return (ntarget + 63) / 64 + (int)target_list_blocks(n); }
 
 int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int t1, uint32_t *tblock, uint32_t *tlist,
                    uint32_t *tcount)

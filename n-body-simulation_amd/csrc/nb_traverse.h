@@ -140,9 +140,19 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
     const int slot = wave * 64 + lane;
     if (wave * 64 >= ntarget)
         return;  // whole wave idle (no block barriers below)
-    const bool valid = slot < ntarget;
+    const uint64_t t_begin = a.wave_cost ? wall_clock64() : 0ull;
+    bool valid = slot < ntarget;
     const int last = valid ? slot : ntarget - 1;
-    const int k = a.tlist ? (int)a.tlist[last] : last;
+    int k = last;
+    if (a.tlist) {
+        // a list of targets comes in groups of 64 entries that start with a target; the rest of a group may be padding
+        // (the group's first entry is read from memory, not from lane 0: written as a select between a lane's entry
+        // and a cross-lane read of the same entry, the compiler folds the read to the padding value the select's
+        // condition implies for that lane)
+        const uint32_t e = a.tlist[slot], e0 = a.tlist[wave * 64];
+        valid = e != TL_PAD;
+        k = (int)(valid ? e : e0);
+    }
     const uint32_t body = a.idx[k];
     // (the FP64 position and radius of the lane's body are read again where the rare FP64
     // re-decisions and the epilogue need them: held in registers they cost a wave per SIMD in 3-D)
@@ -542,6 +552,8 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
         for (int k = 0; k < 8; ++k)
             atomicAdd(&a.counters[8 + k], n_kind[k]);
     }
+    if (a.wave_cost && lane == 0)
+        a.wave_cost[wave] = (uint32_t)(wall_clock64() - t_begin);
     if (!valid)
         return;
     // Where the body's state goes: its own slot, or -- in a step that leaves the bodies in this

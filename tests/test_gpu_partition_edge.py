@@ -84,6 +84,62 @@ def test_ranks_with_an_empty_slice_step_like_the_others(nb, oracle, dims, alg, n
         assert np.allclose(o["vel"][own], ref["vel"][own], rtol=1e-6, atol=1e-6 * np.abs(ref["vel"]).max())
 
 
+@pytest.mark.parametrize("dims", [2, 3])
+def test_targets_that_left_their_ranks_run_of_the_sorted_order(nb, dims):
+    """Seven ranks over ten tiles of the sorted order, thirty steps of two discs that pass through each other: a
+    rank's targets are then one long run of the sorted order plus strays anywhere, and the list of targets gives
+    every tile's targets groups of 64 of their own, padded (tiles shared by ranks, tiles with a single stray).
+    The accelerations the ranks then compute must be those of a handle that is given the same state afresh."""
+    n, world, steps = 20000, 7, 30
+    if dims == 2:
+        b = nb.init_scenario(nb.COLLISION, n, 11)
+        make = lambda: nb.NBodySim(n, nb.BARNES_HUT)  # noqa: E731
+    else:
+        b = nb.init_scenario3(nb.COLLISION, n, 11, 2.0e10)
+        make = lambda: nb.NBodySim3(n, nb.BARNES_HUT)  # noqa: E731
+    hip = _hip()
+    chunk = (n + world - 1) // world
+    ranks = [make() for _ in range(world)]
+    fresh = make()
+    try:
+        for r, s in enumerate(ranks):
+            s.set_bodies(b)
+            s.set_partition(r, world)
+        for _ in range(steps):
+            step_ranks_together(hip, ranks, n)
+        order = ranks[0].order()
+        own = [order[min(n, r * chunk):min(n, (r + 1) * chunk)] for r in range(world)]
+        # the state the ranks hold together: positions from any of them, velocities from their owners
+        state = ranks[0].read_bodies()
+        for r, s in enumerate(ranks):
+            o = s.read_bodies()
+            assert np.array_equal(o["pos"], state["pos"])
+            state["vel"][own[r]] = o["vel"][own[r]]
+        # the accelerations of that state: by a handle of its own, which deals the slots anew (no strays, no list
+        # of targets), and by the ranks as they are
+        fresh.set_bodies(state)
+        fresh.compute_accel()
+        ref = fresh.read_bodies()["acc"]
+        acc = np.zeros_like(ref)
+        for r, s in enumerate(ranks):
+            s.compute_accel()
+            acc[own[r]] = s.read_bodies()["acc"][own[r]]
+        # how far the bodies have wandered: some rank must have targets outside its run of the sorted order
+        sorted_slot = ranks[0].debug(nb.DBG_SORTED_IDX, np.uint32, n)
+    finally:
+        fresh.close()
+        for s in ranks:
+            s.close()
+    rank_of = np.minimum(sorted_slot // chunk, world - 1)
+    assert np.count_nonzero(np.diff(rank_of.astype(np.int64)) != 0) > 4 * world, "no body has left its rank's run"
+    size = np.linalg.norm(ref, axis=1)
+    err = np.linalg.norm(acc - ref, axis=1) / np.maximum(size, 1e-3 * np.median(size))
+    # (the same interactions summed in FP32 by other groups of 64: 1e-6 of the acceleration, more where it is a
+    # small difference of large terms)
+    assert np.median(err) <= 2e-6
+    assert err.max() <= 3e-4
+
+
 def test_partition_is_refused_once_stepped(nb):
     with nb.NBodySim(64, nb.DIRECT) as sim:
         sim.setup(nb.RANDOM, 1)

@@ -133,6 +133,14 @@ def ranks(world, n, steps, cells, scenario=2, alg=None):
         for s in sims:
             s.sync()
         per = [s.stage_ms() for s in sims]
+        if alg == nb.BARNES_HUT:
+            # what the waves of the last traversal of rank 0 and of the last rank took
+            for r in (0, world - 1):
+                nw = ((n + world - 1) // world + 63) // 64
+                c = sims[r].debug(nb.DBG_WAVE_COST, np.uint32, nw).astype(np.float64) * 0.01
+                c = c[c > 0]
+                print("  rank %d: %d waves, mean %.1f us, median %.1f, p99 %.1f, max %.1f; sum / 8192 slots %.1f us" %
+                      (r, len(c), c.mean(), np.median(c), np.percentile(c, 99), c.max(), c.sum() / 8192))
     finally:
         for s in sims:
             s.close()
