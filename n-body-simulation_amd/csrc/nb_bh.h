@@ -49,8 +49,8 @@ struct BhBuffers {
     uint2 *node_child = nullptr;  // x = first child slot << 4 | mask of the child slots in use, y = float
                                   // bits of the prune threshold: (collision_th - cell diagonal)^2, or -1
     uint32_t *tlist = nullptr;    // sorted positions of this rank's targets (multi-GPU), else unused
-    uint32_t *tcount = nullptr;   // 1 entry: number of entries in tlist (groups of 64, see bh_target_list)
-    uint32_t *tblock = nullptr;   // per-block target counts (scratch of the compaction)
+    uint32_t *tcount = nullptr;   // 2 entries used in turn: number of entries in tlist (groups of 64, see bh_target_list)
+    unsigned tl_calls = 0;        // lists built so far
     unsigned long long *counters = nullptr;  // 16 statistics words (NB_DBG_COUNTERS, NB_DBG_VISIT_KINDS)
     uint32_t *wave_cost = nullptr;           // what each 64-body group of the last traversal took, in 10 ns ticks (NB_DBG_WAVE_COST)
     uint32_t *levels_host = nullptr;  // pinned host word: tree levels of the last finished step
@@ -141,13 +141,14 @@ int build_tree(hipStream_t s, int bits, const uint64_t *keys, int n, uint4 *node
 // Sorted positions k whose body sorted_idx[k] lies in [t0, t1), ascending, into tlist (target_list_capacity(n)
 // words) in groups of 64 entries: the targets of every tile of the sorted order start a group of their own, and
 // the entries a tile's last group has left over are TL_PAD.  The number of entries, a multiple of 64, into
-// *tcount (at most 64 target_list_groups(n, t1 - t0)); tblock: target_list_blocks(n) words of scratch.
+// **count (at most 64 target_list_groups(n, t1 - t0)); the tiles' groups come in any order.  tcount: two words,
+// both zero before the first call, used in turn (`calls` counts the calls; *count is the one this call used).
 constexpr uint32_t TL_PAD = 0xffffffffu;
 size_t target_list_blocks(int n);
 size_t target_list_capacity(int n);
 int target_list_groups(int n, int ntarget);
-int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int t1, uint32_t *tblock, uint32_t *tlist,
-                   uint32_t *tcount);
+int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int t1, uint32_t *tlist, uint32_t *tcount,
+                   unsigned &calls, const uint32_t **count);
 // Second half of the leaf pass: adds to every run of equal keys that crosses 64-body chunk
 // boundaries the parts its chunks left in leaf_sum (dims 2: slots of 4 doubles {3 sums, max
 // radius}; 3: slots of 6 doubles {4 sums, max radius, -}); chunk_info: see nb_dev.h.

@@ -492,9 +492,8 @@ int bh_force(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
     int ntarget = a.n;
     if (a.t0 != 0 || a.t1 != a.n) {
         // this rank integrates only bodies [t0, t1): walk them in the sorted order
-        NB_TRY(bh_target_list(s, b.idx[b.sorted], a.n, a.t0, a.t1, b.tblock, b.tlist, b.tcount));
+        NB_TRY(bh_target_list(s, b.idx[b.sorted], a.n, a.t0, a.t1, b.tlist, b.tcount, b.tl_calls, &f.tcount));
         f.tlist = b.tlist;
-        f.tcount = b.tcount;
         ntarget = a.t1 - a.t0;
     }
     f.dyn = a.dyn;
@@ -570,7 +569,6 @@ static int bh_layout(BhBuffers &b, int n, bool with_pyramid, Alloc &&alloc)
     NB_TRY(alloc(b.node_child, b.node_cap));
     NB_TRY(alloc(b.tlist, target_list_capacity(n)));
     NB_TRY(alloc(b.tcount, 4));
-    NB_TRY(alloc(b.tblock, target_list_blocks(n)));
     NB_TRY(alloc(b.counters, 16));
     NB_TRY(alloc(b.wave_cost, (size_t)target_list_groups(n, n) + 2));
     if (with_pyramid) {
@@ -584,6 +582,7 @@ int bh_alloc(BhBuffers &b, int n)
 {
     b.owned = true;
     NB_TRY(bh_layout(b, n, true, [](auto *&p, size_t count) { return dev_alloc(p, count); }));
+    NB_HIP(hipMemset(b.tcount, 0, 4 * sizeof(uint32_t)));  // bh_target_list's words
     void *h = nullptr;
     if (hipHostMalloc(&h, 64 + sizeof(double) * BOX_SLOT * BOX_RING, hipHostMallocDefault) != hipSuccess)
         return fail(NB_ERR_NOMEM, "hipHostMalloc failed");
@@ -649,7 +648,6 @@ void bh_free(BhBuffers &b)
         (void)hipFree(b.node_child);
         (void)hipFree(b.tlist);
         (void)hipFree(b.tcount);
-        (void)hipFree(b.tblock);
         (void)hipFree(b.counters);
         (void)hipFree(b.wave_cost);
         (void)hipFree(b.pc_range);

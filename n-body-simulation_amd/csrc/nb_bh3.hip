@@ -574,9 +574,8 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     int ntarget = a.n;
     if (a.t0 != 0 || a.t1 != a.n) {
         // this rank integrates only bodies [t0, t1): walk them in the sorted order
-        NB_TRY(bh_target_list(s, b.idx[0], a.n, a.t0, a.t1, b.tblock, b.tlist, b.tcount));
+        NB_TRY(bh_target_list(s, b.idx[0], a.n, a.t0, a.t1, b.tlist, b.tcount, b.tl_calls, &f.tcount));
         f.tlist = b.tlist;
-        f.tcount = b.tcount;
         ntarget = a.t1 - a.t0;
     }
     if (ntarget <= 0)
@@ -647,7 +646,7 @@ int bh3_alloc(Bh3Buffers &b, int n)
     NB_TRY(dev_alloc(b.node_aux, b.node_cap));
     NB_TRY(dev_alloc(b.tlist, target_list_capacity(n)));
     NB_TRY(dev_alloc(b.tcount, 4));
-    NB_TRY(dev_alloc(b.tblock, target_list_blocks(n)));
+    NB_HIP(hipMemset(b.tcount, 0, 4 * sizeof(uint32_t)));
     NB_TRY(dev_alloc(b.counters, 16));
     void *h = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
@@ -681,7 +680,6 @@ void bh3_free(Bh3Buffers &b)
     (void)hipFree(b.node_aux);
     (void)hipFree(b.tlist);
     (void)hipFree(b.tcount);
-    (void)hipFree(b.tblock);
     (void)hipFree(b.counters);
     if (b.levels_host)
         (void)hipHostFree(b.levels_host);

@@ -365,26 +365,14 @@ int bh_sort(hipStream_t s, BhBuffers &b, const BhStepArgs &a)
 constexpr int TL_ITEMS = 8;
 constexpr int TL_TILE = 256 * TL_ITEMS;
 
-__global__ __launch_bounds__(256) void k_tl_count(const uint32_t *idx, int n, uint32_t t0, uint32_t t1, uint32_t *bcount)
+// One launch: a block per tile counts its targets, takes room for its groups at the end of the list by one atomic
+// add, and writes them.  The tiles' groups therefore come in any order -- every group is walked by a wave of its
+// own, so the order is a matter of placement only.  `count` must be zero when the launch starts: the launch
+// leaves `count_next`, the word the launch after it will use, at zero (the traversal that read it has finished).
+__global__ __launch_bounds__(256) void k_tl_build(const uint32_t *idx, int n, uint32_t t0, uint32_t t1, uint32_t *tlist,
+                                                  uint32_t *count, uint32_t *count_next)
 {
-    const int base = blockIdx.x * TL_TILE + threadIdx.x * TL_ITEMS;
-    int c = 0;
-#pragma unroll
-    for (int it = 0; it < TL_ITEMS; ++it) {
-        const int k = base + it;
-        if (k < n) {
-            const uint32_t o = idx[k];
-            c += (o >= t0 && o < t1) ? 1 : 0;
-        }
-    }
-    const int tot = block_sum_256(c);
-    if (threadIdx.x == 0)
-        bcount[blockIdx.x] = (uint32_t)((tot + 63) & ~63);
-}
-
-__global__ __launch_bounds__(256) void k_tl_emit(const uint32_t *idx, int n, uint32_t t0, uint32_t t1,
-                                                 const uint32_t *bcount_excl, uint32_t *tlist, uint32_t *tcount)
-{
+    __shared__ uint32_t s_first;
     const int base = blockIdx.x * TL_TILE + threadIdx.x * TL_ITEMS;
     bool own[TL_ITEMS];
     int c = 0;
@@ -399,31 +387,37 @@ __global__ __launch_bounds__(256) void k_tl_emit(const uint32_t *idx, int n, uin
         c += own[it] ? 1 : 0;
     }
     int tot;
-    const int first = (int)bcount_excl[blockIdx.x];
-    int pos = first + block_excl_scan_256(c, tot);
+    const int before = block_excl_scan_256(c, tot);
+    const int padded = (tot + 63) & ~63;
+    if (threadIdx.x == 0) {
+        s_first = padded ? atomicAdd(count, (uint32_t)padded) : 0u;
+        if (blockIdx.x == 0)
+            *count_next = 0u;
+    }
+    __syncthreads();
+    const int first = (int)s_first;
+    int pos = first + before;
 #pragma unroll
     for (int it = 0; it < TL_ITEMS; ++it)
         if (own[it])
             tlist[pos++] = (uint32_t)(base + it);
-    const int padded = (tot + 63) & ~63;
     if ((int)threadIdx.x < padded - tot)  // at most 63 entries
         tlist[first + tot + (int)threadIdx.x] = TL_PAD;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-        *tcount = (uint32_t)(first + padded);
 }
 
 size_t target_list_blocks(int n) { return (size_t)(n + TL_TILE - 1) / TL_TILE + 1; }
 size_t target_list_capacity(int n) { return (size_t)n + 64 * target_list_blocks(n); }
 int target_list_groups(int n, int ntarget) { return (ntarget + 63) / 64 + (int)target_list_blocks(n); }
 
-int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int t1, uint32_t *tblock, uint32_t *tlist,
-                   uint32_t *tcount)
+int bh_target_list(hipStream_t s, const uint32_t *sorted_idx, int n, int t0, int t1, uint32_t *tlist, uint32_t *tcount,
+                   unsigned &calls, const uint32_t **count)
 {
     const int nblk = (n + TL_TILE - 1) / TL_TILE;
-    hipLaunchKernelGGL(k_tl_count, dim3(nblk), dim3(256), 0, s, sorted_idx, n, (uint32_t)t0, (uint32_t)t1, tblock);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, tblock, nblk);
-    hipLaunchKernelGGL(k_tl_emit, dim3(nblk), dim3(256), 0, s, sorted_idx, n, (uint32_t)t0, (uint32_t)t1, tblock, tlist, tcount);
+    uint32_t *mine = tcount + (calls & 1u), *next = tcount + ((calls + 1u) & 1u);
+    hipLaunchKernelGGL(k_tl_build, dim3(nblk), dim3(256), 0, s, sorted_idx, n, (uint32_t)t0, (uint32_t)t1, tlist, mine, next);
     NB_HIP(hipGetLastError());
+    calls += 1u;
+    *count = mine;
     return NB_OK;
 }
 

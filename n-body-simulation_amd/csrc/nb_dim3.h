@@ -76,8 +76,8 @@ struct Bh3Buffers {
                                   // leaf; y = first child << 4 | child count; z = float bits of the prune
                                   // threshold (collision_th - cell diagonal)^2 or -1
     uint32_t *tlist = nullptr;    // sorted positions of this rank's targets (partitioned runs)
-    uint32_t *tcount = nullptr;
-    uint32_t *tblock = nullptr;
+    uint32_t *tcount = nullptr;   // 2 entries used in turn (bh_target_list)
+    unsigned tl_calls = 0;
     unsigned long long *counters = nullptr;
     uint32_t *levels_host = nullptr;
     int launched = 0;
