@@ -141,6 +141,7 @@ def ranks(world, n, steps, cells, scenario=2, alg=None):
                 c = c[c > 0]
                 print("  rank %d: %d waves, mean %.1f us, median %.1f, p99 %.1f, max %.1f; sum / 8192 slots %.1f us" %
                       (r, len(c), c.mean(), np.median(c), np.percentile(c, 99), c.max(), c.sum() / 8192))
+                print("    slowest (index: us): " + ", ".join("%d: %.0f" % (i, c[i]) for i in np.argsort(-c)[:8]))
     finally:
         for s in sims:
             s.close()
