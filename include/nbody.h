@@ -382,7 +382,7 @@ int nb3_step_distributed(nb_sim3 *sim, int nsteps);
  * (topLeft.x, topLeft.y, botRight.x, botRight.y, upper z, lower z); keys hold 3 bits per level from
  * bit 61 down (at most 20 levels: bodies that share a cell of level 20, a millionth of the box, share a
  * leaf and act as one body at their centre of mass, as bodies sharing all 31 levels do in 2-D); NB_DBG_NODE_COM is 6 doubles per node (com.x, com.y, com.z, mass,
- * cell x-width or minus the body's radius, 0); NB_DBG_KEYS and NB_DBG_WAVE_COST are not available. */
+ * cell x-width or minus the body's radius, 0); NB_DBG_KEYS is not available. */
 int nb3_debug_read(nb_sim3 *sim, int which, void *out, size_t bytes, size_t *written);
 /* out[0] total mass, [1..3] centre of mass, [4..6] momentum, [7..9] angular momentum about the origin,
  * [10] kinetic energy, [11] potential energy (NaN when n > 131072), as nb_diagnostics defines them. */

@@ -323,6 +323,8 @@ int nb3_debug_read(nb_sim3 *s, int which, void *out, size_t bytes, size_t *writt
         return give(s->bh.cut, sizeof(uint32_t) * 2, true);
     case NB_DBG_COUNTERS:
         return give(s->bh.counters, sizeof(unsigned long long) * 8, true);
+    case NB_DBG_WAVE_COST:
+        return give(s->bh.wave_cost, sizeof(uint32_t) * (((size_t)(s->t1 - s->t0) + 63) / 64), true);
     case NB_DBG_VISIT_KINDS:
         return give(s->bh.counters + 8, sizeof(unsigned long long) * 8, true);
     default:

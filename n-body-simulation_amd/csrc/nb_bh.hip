@@ -21,8 +21,6 @@
 //              (barnesHut.cpp:108-123) is fused into the epilogue.
 #include <cmath>
 #include <type_traits>
-#include <cmath>
-#include <type_traits>
 
 #include "nb_bh_internal.h"
 #include "nb_traverse.h"

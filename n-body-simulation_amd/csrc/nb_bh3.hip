@@ -586,7 +586,7 @@ int bh3_force(hipStream_t s, Bh3Buffers &b, const Bh3StepArgs &a)
     f.vel = a.vel;
     f.acc = a.acc;
     f.counters = b.counters;
-    f.wave_cost = nullptr;
+    f.wave_cost = b.wave_cost;
     f.n = a.n;
     f.fc = a.fc;
     f.ia = a.ia;
@@ -648,6 +648,7 @@ int bh3_alloc(Bh3Buffers &b, int n)
     NB_TRY(dev_alloc(b.tcount, 4));
     NB_HIP(hipMemset(b.tcount, 0, 4 * sizeof(uint32_t)));
     NB_TRY(dev_alloc(b.counters, 16));
+    NB_TRY(dev_alloc(b.wave_cost, (size_t)target_list_groups(n, n) + 2));
     void *h = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess)
         return fail(NB_ERR_NOMEM, "hipHostMalloc failed");
@@ -681,6 +682,7 @@ void bh3_free(Bh3Buffers &b)
     (void)hipFree(b.tlist);
     (void)hipFree(b.tcount);
     (void)hipFree(b.counters);
+    (void)hipFree(b.wave_cost);
     if (b.levels_host)
         (void)hipHostFree(b.levels_host);
     b = Bh3Buffers();

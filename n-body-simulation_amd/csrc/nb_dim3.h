@@ -79,6 +79,7 @@ struct Bh3Buffers {
     uint32_t *tcount = nullptr;   // 2 entries used in turn (bh_target_list)
     unsigned tl_calls = 0;
     unsigned long long *counters = nullptr;
+    uint32_t *wave_cost = nullptr;  // as BhBuffers::wave_cost
     uint32_t *levels_host = nullptr;
     int launched = 0;
 };

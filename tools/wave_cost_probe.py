@@ -38,7 +38,7 @@ def makespan(cost, wave_of_block):
     return worst
 
 
-def main():
+def main():  # noqa: C901
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
     at = [int(v) for v in sys.argv[2:]] or [10, 300]
     sim = nb.NBodySim(n, nb.BARNES_HUT)
@@ -68,6 +68,22 @@ def main():
             print("   model: waves above %.1f x mean first (in index order), the rest as now: %.1f us" % (f, makespan(c, order)))
             order = list(heavy[np.argsort(-c[heavy])]) + [w for w in now if not flag[w]]
             print("          the same, the heavy ones by cost: %.1f us" % makespan(c, order), flush=True)
+        # cheaper orders than a full sort: Q tiers of equal cost range, heaviest tier first, each tier in the order in
+        # use now; and runs of 32 consecutive waves (what one XCD is dealt at a time) sorted by their mean cost
+        for q in (4, 16, 64):
+            lo, hi = c.min(), np.percentile(c, 99.9)
+            tier = np.clip(((hi - c) / (hi - lo) * q).astype(int), 0, q - 1)  # 0 = heaviest
+            nowa = np.array(now)
+            order = list(nowa[np.argsort(tier[nowa], kind="stable")])
+            print("   model: %d tiers by cost, heaviest first: %.1f us" % (q, makespan(c, order)))
+        nch = nw // CHUNK
+        chunk_cost = c[:nch * CHUNK].reshape(nch, CHUNK).mean(axis=1)
+        chunks = np.argsort(-chunk_cost)
+        # chunk j of the sorted list goes where logical chunk j goes now: dispatch position -> logical wave -> sorted chunk
+        order = []
+        for w in now:
+            order.append(int(chunks[w // CHUNK]) * CHUNK + w % CHUNK if w < nch * CHUNK else w)
+        print("   model: runs of %d waves sorted by their mean cost: %.1f us" % (CHUNK, makespan(c, order)), flush=True)
         # where along the order the heavy waves lie
         q = np.add.reduceat(c, np.arange(0, nw, max(1, nw // 16))) / c.sum()
         print("   share of the time per sixteenth of the order: " + " ".join("%.3f" % v for v in q[:16]))
