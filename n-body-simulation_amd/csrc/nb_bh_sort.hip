@@ -186,6 +186,17 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
     // are moved with the keys, and the last pass takes the pairs apart again
     const bool packed = cut[5] != 0u;
     const bool unpack = packed && pass == SORT_PASSES - 1;
+    // thread = digit: the digit's keys in all blocks, in the segments of the row before this block's own, and
+    // in the blocks of its segment before this one -- asked for here, ahead of the keys, and used after the ranking
+    const int myseg = (int)blockIdx.x / ((nblk + SORT_SEGS - 1) / SORT_SEGS);
+    uint32_t digit_total = 0, segs_before = 0;
+#pragma unroll
+    for (int g = 0; g < SORT_SEGS; ++g) {
+        const uint32_t v = totals[tid * SORT_SEGS + g];
+        digit_total += v;
+        segs_before += g < myseg ? v : 0u;
+    }
+    const uint32_t in_segment_before = hist[(size_t)tid * nblk + blockIdx.x];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         wcnt[k][tid] = 0;
@@ -197,12 +208,19 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
     uint32_t rank[SORT_ITEMS];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     volatile uint32_t *mycnt = wcnt[w];
+    // every load of the thread is asked for before the first is used: inside the ranking loop, whose wave
+    // barriers order memory operations, each round would wait for its own trip to memory (eight in a row)
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const int i = chunk + it * 64 + lane;
         const bool valid = i < n;
         key[it] = valid ? keys_in[i] : ~0ull;
         val[it] = (valid && !packed) ? idx_in[i] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const int i = chunk + it * 64 + lane;
+        const bool valid = i < n;
         const uint32_t d = sort_digit(key[it], pass);
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -235,19 +253,10 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t *keys_in, c
         }
         int all;
         const int local_start = block_excl_scan_256((int)run, all);
-        // the digit's keys in all blocks, and in the segments of the row before this block's own
-        const int myseg = (int)blockIdx.x / ((nblk + SORT_SEGS - 1) / SORT_SEGS);
-        uint32_t digit_total = 0, segs_before = 0;
-#pragma unroll
-        for (int g = 0; g < SORT_SEGS; ++g) {
-            const uint32_t v = totals[tid * SORT_SEGS + g];
-            digit_total += v;
-            segs_before += g < myseg ? v : 0u;
-        }
         // start of digit `tid` in the output = keys with a smaller digit (scan of the 256 totals)
         const int before = block_excl_scan_256((int)digit_total, all);
         lstart[tid] = (uint32_t)local_start;
-        dbase[tid] = (uint32_t)before + segs_before + hist[(size_t)tid * nblk + blockIdx.x] - (uint32_t)local_start;
+        dbase[tid] = (uint32_t)before + segs_before + in_segment_before - (uint32_t)local_start;
     }
     __syncthreads();
     // Keys go through LDS in the block's sorted order, so that consecutive threads write
