@@ -759,3 +759,30 @@ def test_sort_is_finished_when_the_keys_outgrow_the_launched_passes(nb, oracle, 
             assert np.array_equal(sim.debug(nb.DBG_SORTED_KEYS, np.uint64, n), ref_keys[order])
             assert np.array_equal(sim.debug(nb.DBG_SORTED_IDX, np.uint32, n), order.astype(np.uint32))
     assert before <= 10 and levels >= before + 8, (before, levels)
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_every_group_of_targets_reports_what_its_wave_took(nb, dims):
+    """NB_DBG_WAVE_COST: one entry per group of 64 consecutive targets of the last traversal, in ticks of 10 ns; a wave
+    that walked the tree took at least a microsecond and far less than a second."""
+    n = 10000 + 37
+    if dims == 2:
+        sim = nb.NBodySim(n, nb.BARNES_HUT)
+        b = nb.init_scenario(nb.COLLISION, n, 5)
+    else:
+        sim = nb.NBodySim3(n, nb.BARNES_HUT)
+        b = nb.init_scenario3(nb.COLLISION, n, 5, 2.0e10)
+    with sim:
+        sim.set_bodies(b)
+        sim.update(2)
+        groups = (n + 63) // 64
+        cost = sim.debug(nb.DBG_WAVE_COST, np.uint32, groups)
+        assert cost.shape == (groups,)
+        assert cost.min() >= 100 and cost.max() < 100_000_000
+        # a rank of a partitioned run reports the groups of its own targets
+        sim.set_bodies(b)
+        sim.set_partition(1, 3)
+        sim.compute_accel()
+        own = (n + 2) // 3
+        cost = sim.debug(nb.DBG_WAVE_COST, np.uint32, (own + 63) // 64)
+        assert cost.min() >= 100 and cost.max() < 100_000_000
