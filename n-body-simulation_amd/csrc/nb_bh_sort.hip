@@ -98,40 +98,6 @@ __global__ __launch_bounds__(256) void k_sort_count(const uint64_t *keys, int n,
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
-// Exclusive scan of `count` uint32 in place, one 1024-thread block.
-__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *data, int count)
-{
-    __shared__ uint32_t wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int per = (count + 1023) / 1024;
-    const int beg = tid * per;
-    int end = beg + per;
-    if (end > count)
-        end = count;
-    uint32_t sum = 0;
-    for (int i = beg; i < end; ++i)
-        sum += data[i];
-    uint32_t incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(incl, o);
-        if (lane >= o)
-            incl += t;
-    }
-    if (lane == 63)
-        wsum[w] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int k = 0; k < w; ++k)
-        base += wsum[k];
-    uint32_t run = base + incl - sum;
-    for (int i = beg; i < end; ++i) {
-        uint32_t v = data[i];
-        data[i] = run;
-        run += v;
-    }
-}
-
 // Sort pass, step 2: the per-block counts of every digit turned into running offsets.  A digit's
 // row (hist[d][0..nblk)) is cut into SORT_SEGS segments, one block each: exclusive scan of the
 // segment in place, the segment's total into totals[d][segment]; the scatter adds the totals of
