@@ -99,6 +99,18 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
 template <int DIM>
 struct Traversal;
 
+// A staged 16-byte record read whole.  Where a loop needs only three of its words the compiler narrows the read to a
+// ds_read_b96, which the LDS serves in eight cycles per wave against four for a ds_read_b128 -- and the LDS array of
+// a CU, shared by the visits of its four SIMDs, is as busy as the vector pipes in this kernel.
+static __device__ __forceinline__ uint4 lds_read_whole(const uint4 *p)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // (volatile: the compiler may not narrow the read; the pointer is named as one into LDS again, which the cast
+    // to a volatile type would otherwise forget)
+    const u32x4 v = *(const volatile __attribute__((address_space(3))) u32x4 *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // The stack holds one entry per opened node: {first child slot << 4 | which of its child slots are
 // in use, mask of the lanes that opened it}; the siblings share the lane mask.  A round pops up to
 // ENTRIES entries and gives each a group of GROUP lanes: lane GROUP e + i takes child slot i of the
@@ -381,7 +393,7 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
         // ---- cells: accepted when width / dist < theta (barnesHut.cpp:70-71), else opened ----
         auto visit_cell = [&](const int j, auto far_tag) {
             constexpr bool FAR = decltype(far_tag)::value;
-            const uint4 r = batch[j][0], q = batch[j][1];
+            const uint4 r = lds_read_whole(&batch[j][0]), q = lds_read_whole(&batch[j][1]);
             const float4 rf = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
             const float cw = T::staged_width(rf, q);
             const uint64_t mj = lanes_of(q);
@@ -443,7 +455,7 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
         // the compiler's own choice (8) costs 16 registers, i.e. two of the eight waves per SIMD. ----
 #pragma unroll 2
         for (int j = 0; j < nfull; ++j) {
-            const uint4 r = batch[j][0];
+            const uint4 r = lds_read_whole(&batch[j][0]);
             const float4 rf = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
             const Pt<DIM> dv = pt_sub(T::point(rf), xi);
             const float d2 = pt_norm2(dv);
@@ -456,7 +468,7 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
         }
         // ---- cells every lane accepts: only the force, for the lanes the cell is visited for ----
         for (int j = nfull; j < nsure; ++j) {
-            const uint4 r = batch[j][0];
+            const uint4 r = lds_read_whole(&batch[j][0]);
             const uint2 q2 = *(const uint2 *)&batch[j][1];
             const float4 rf = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
             const uint64_t mj = lanes_of(make_uint4(q2.x, q2.y, 0u, 0u));
@@ -474,7 +486,7 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
             visit_cell(j, std::true_type{});
         // ---- cells whose acceptance is settled: counted outside 2 r_i + th of the centre of mass ----
         for (int j = nfar; j < ndrop; ++j) {
-            const uint4 r = batch[j][0];
+            const uint4 r = lds_read_whole(&batch[j][0]);
             const uint2 q2 = *(const uint2 *)&batch[j][1];
             const float4 rf = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
             const uint64_t mj = lanes_of(make_uint4(q2.x, q2.y, 0u, 0u));
@@ -504,7 +516,7 @@ __device__ __forceinline__ void traverse_and_integrate(const typename Traversal<
             visit_cell(j, std::false_type{});
         // ---- bodies: skipped when r_i + r_j + th > dist (barnesHut.cpp:59,125-129) ----
         for (int j = ncell; j < cstaged; ++j) {
-            const uint4 r = batch[j][0], q = batch[j][1];
+            const uint4 r = lds_read_whole(&batch[j][0]), q = lds_read_whole(&batch[j][1]);
             const float4 rf = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
             const float bw = T::staged_width(rf, q);  // -(r_j + th)
             const uint64_t mj = lanes_of(q);
