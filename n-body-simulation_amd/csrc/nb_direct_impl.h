@@ -362,6 +362,18 @@ __device__ __forceinline__ void redo_ambiguous(const DirectArgs<DIM> &a, const f
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// A staged record read whole from LDS.  A loop that needs three of its four words gets a ds_read_b96 from the
+// compiler, which the LDS serves in eight cycles per wave where a ds_read_b128 takes four; every wave of a block reads
+// the same record at a time, and with four SIMDs issuing 26 cycles of arithmetic per record the eight-cycle read made
+// the LDS the busier unit in three dimensions.  (volatile: the read may not be narrowed; the pointer is named as one
+// into LDS again, which the cast would otherwise forget.)
+static __device__ __forceinline__ float4 lds_record_whole(const float4 *p)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 v = *(const volatile __attribute__((address_space(3))) f32x4 *)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // All pairs of this thread's TPT targets with one run of T::SUB staged records, on packed FP32
 // (v_pk_add/mul/fma_f32: two lanes of arithmetic per issue slot): targets are taken two at a time,
 // so every operation but the reciprocal square root and the comparisons serves two pairs.
@@ -417,7 +429,9 @@ __device__ __forceinline__ void run_pairs(const DirectArgs<DIM> &a, const float4
         }
 #pragma unroll UNROLL
         for (int jj = 0; jj < T::FLUSH; ++jj) {
-            const float4 b = rec[c + jj];
+            // two words (2-D, uniform mass) are a ds_read_b64; three would be a ds_read_b96: read all four then
+            constexpr bool WHOLE = !(DIM == 2 && UNIFORM && !CUTOFF);
+            const float4 b = WHOLE ? lds_record_whole(rec + c + jj) : rec[c + jj];
             float bc[DIM];
             T::coords(b, bc);
             const float m = T::mass(b);
