@@ -367,7 +367,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // the same record at a time, and with four SIMDs issuing 26 cycles of arithmetic per record the eight-cycle read made
 // the LDS the busier unit in three dimensions.  (volatile: the read may not be narrowed; the pointer is named as one
 // into LDS again, which the cast would otherwise forget.)
-static __device__ __forceinline__ float4 lds_record_whole(const float4 *p)
+static __device__ __forceinline__ float4 lds_record_whole(const float4 *p)  // p: a record in LDS, nowhere else
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 v = *(const volatile __attribute__((address_space(3))) f32x4 *)p;

@@ -102,7 +102,7 @@ struct Traversal;
 // A staged 16-byte record read whole.  Where a loop needs only three of its words the compiler narrows the read to a
 // ds_read_b96, which the LDS serves in eight cycles per wave against four for a ds_read_b128 -- and the LDS array of
 // a CU, shared by the visits of its four SIMDs, is as busy as the vector pipes in this kernel.
-static __device__ __forceinline__ uint4 lds_read_whole(const uint4 *p)
+static __device__ __forceinline__ uint4 lds_read_whole(const uint4 *p)  // p: a record in LDS, nowhere else
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     // (volatile: the compiler may not narrow the read; the pointer is named as one into LDS again, which the cast
